@@ -1,0 +1,236 @@
+/*
+ * viddet_hip.h — C-ABI of libviddet_hip.so, the MI355X (gfx950) kernel library behind the
+ * yolo3_darknet53 train / detect hot path.
+ *
+ * The reference (HaydenFaulkner/VidDet) has no FFI: its hot path is a Gluon HybridBlock that
+ * composes MXNet/GluonCV operators.  Each entry point below therefore names the reference
+ * *operator call site* (file:line under /root/reference) whose arithmetic it replaces.  The
+ * Python host (viddet_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, <0 = VD_E* ; vd_last_error() gives a thread-local text.
+ *  - the library never allocates or frees device memory: every buffer (incl. workspaces) is
+ *    owned by the caller; pointers are raw device addresses.
+ *  - `stream` is a hipStream_t passed as void*; ordering is by stream only; calls are
+ *    asynchronous and re-entrant.
+ *  - activations are NHWC fp32 (bf16 where stated); conv weights arrive in the reference's OIHW
+ *    layout and are re-packed by vd_pack_* into the K-contiguous layouts the kernels read.
+ */
+#ifndef VIDDET_HIP_H
+#define VIDDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD_OK            0
+#define VD_EINVAL       -1   /* bad argument / unsupported shape */
+#define VD_ELAUNCH      -2   /* hip launch error */
+#define VD_EWORKSPACE   -3   /* workspace too small */
+
+#define VD_MAX_TAPS 27
+
+/* epilogue flags of vd_conv_igemm */
+#define VD_EPI_AFFINE    1   /* v = v*scale[c] + shift[c]   (BN-eval fold, or bias with scale==NULL) */
+#define VD_EPI_LEAKY     2   /* v = v>0 ? v : slope*v */
+#define VD_EPI_RESIDUAL  4   /* v += residual[m][c]  (after the activation) */
+
+const char* vd_last_error(void);
+int vd_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Generic tap-list implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ *   out[n, gy*os+oy, gx*os+ox, co] = epi( sum_{t<T} sum_{ci<Ci}
+ *          in[n, gy*is+dy[t], gx*is+dx[t], ci] * wp[co][t*Ci + ci] )        (zero outside the image)
+ *
+ * One kernel serves: forward 1x1/3x3 s1/s2 (layers.py:66-67 nn.Conv2D inside _conv2d;
+ * yolo3.py:62 prediction conv), the 3-tap / 27-tap temporal convs (layers.py:73-89), and the
+ * data gradient of all of them (autograd.backward, train_yolov3.py:631) through flipped /
+ * parity-split tap lists built by the host.
+ * Requirements: Ci % 32 == 0; in/out 16-byte aligned; ldo >= Co (output pixel pitch in floats).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* in;        /* [N, Hi, Wi, Ci] */
+    const float* wp;        /* [Co][T*Ci] packed, k contiguous */
+    float*       out;       /* [N, Ho, Wo, ldo] */
+    const float* scale;     /* [Co] or NULL */
+    const float* shift;     /* [Co] or NULL */
+    const float* residual;  /* same geometry as out, pitch ldr, or NULL */
+    int32_t N, Hi, Wi, Ci;
+    int32_t Hg, Wg;         /* GEMM row grid per image */
+    int32_t in_stride;      /* is */
+    int32_t T;
+    int32_t dy[VD_MAX_TAPS], dx[VD_MAX_TAPS];
+    int32_t dz[VD_MAX_TAPS];/* temporal tap offset (frames); 0 for 2-D convs */
+    int32_t Kfr;            /* frames per window for temporal convs (N = windows*Kfr); 1 otherwise */
+    int32_t Ho, Wo, Co;
+    int32_t out_stride, out_oy, out_ox;
+    int32_t ldo, ldr;
+    int32_t flags;
+    float   slope;
+    /* in-load transform: the A operand is leaky(in*in_scale[ci]+in_shift[ci]) when in_scale!=NULL
+     * (fuses the producer's BatchNorm+LeakyReLU into this conv's gather; padding stays 0) */
+    const float* in_scale;
+    const float* in_shift;
+    float   in_slope;
+} vd_conv_desc;
+
+int vd_conv_igemm(const vd_conv_desc* d, void* stream);
+
+/* Weight gradient (autograd.backward wrt nn.Conv2D weight, train_yolov3.py:631):
+ *   dwp[co][t*Ci+ci] = sum_{n,gy,gx} dout[n,gy,gx,co] * in[n, gy*is+dy[t], gx*is+dx[t], ci]
+ * split over `splits` pixel ranges into workspace slabs, then reduced deterministically.
+ * ws must hold vd_conv_wgrad_ws_bytes() bytes. */
+typedef struct {
+    const float* in;        /* [N, Hi, Wi, Ci] */
+    const float* dout;      /* [N, Hg, Wg, ldd] */
+    float*       dwp;       /* [Co][T*Ci] */
+    int32_t N, Hi, Wi, Ci;
+    int32_t Hg, Wg, Co, ldd;
+    int32_t in_stride;
+    int32_t T;
+    int32_t dy[VD_MAX_TAPS], dx[VD_MAX_TAPS];
+    int32_t dz[VD_MAX_TAPS];
+    int32_t Kfr;
+    int32_t splits;         /* 0 = choose */
+    const float* in_scale;  /* optional in-load transform as in vd_conv_desc */
+    const float* in_shift;
+    float   in_slope;
+} vd_wgrad_desc;
+
+int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d);
+int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stream);
+
+/* Stem conv 3->32 3x3 s1 p1 (three_darknet.py:163-164): Ci=3 is too thin for the GEMM path, so
+ * the stem is lowered to an explicit 32-wide im2col ( col[n,y,x,(ky*3+kx)*3+c], entries 27..31
+ * zero ) followed by vd_conv_igemm / vd_conv_wgrad with T=1, Ci=32.  `in` is [N,H,W,3] (nchw=0)
+ * or the reference's [N,3,H,W] batch layout (nchw=1, transforms.py:239-245). */
+int vd_stem_im2col(const float* in, float* col, int N, int H, int W, int nchw, void* stream);
+
+/* OIHW -> packed [Co_pad][T*Ci] (forward) ; rows >= Co are zero.  kd = temporal kernel depth (1 for 2-D). */
+int vd_pack_weight_fwd(const float* w_oihw, float* wp, int Co, int Co_pad, int Ci,
+                       int kd, int kh, int kw, void* stream);
+/* OIHW -> dgrad pack [Ci][T'*Co_pad] for the tap subset `taps` (indices into kd*kh*kw, already
+ * in the order the dgrad tap list uses; HOST pointer).  src_packed=1: w is already in the
+ * forward-packed layout [Co][T*Ci] (the layout the parameter arena keeps) instead of OIHW. */
+int vd_pack_weight_dgrad(const float* w_oihw, float* wp, int Co, int Co_pad, int Ci,
+                         int kd, int kh, int kw, const int32_t* taps, int ntaps, int src_packed,
+                         void* stream);
+/* packed gradient [Co_pad][T*Ci] -> OIHW [Co][Ci][kd][kh][kw] (accumulate=0 overwrites) */
+int vd_unpack_wgrad(const float* dwp, float* dw_oihw, int Co, int Ci, int kd, int kh, int kw,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm (layers.py:68 norm_layer(epsilon=1e-5, momentum=0.9)) + LeakyReLU(0.1) (layers.py:69)
+ * on NHWC [M, C] (M = N*H*W).
+ * ------------------------------------------------------------------------------------- */
+/* partial sums: sums[0..C) = sum x, sums[C..2C) = sum x^2 (fp64 accumulators, deterministic) */
+int64_t vd_bn_stats_ws_bytes(int64_t M, int C);
+int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes,
+                void* stream);
+/* from (possibly all-reduced) sums and total count: mean, biased var -> scale/shift for the
+ * apply, saved mean/invstd for backward, running-stat update run = mom*run + (1-mom)*batch */
+int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* eval: scale/shift from running stats */
+int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, float eps, int C, float* scale, float* shift,
+                    void* stream);
+/* y = leaky(x*scale+shift) (+ residual) */
+int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, const float* residual,
+                      float* y, int64_t M, int C, float slope, void* stream);
+/* backward, pass 1: partial sums of g=dy*leaky'(.) and g*xhat -> sums2[0..C)=sum g, [C..2C)=sum g*xhat */
+int vd_bn_bwd_reduce(const float* x, const float* dy, const float* scale, const float* shift,
+                     const float* save_mean, const float* save_invstd, int64_t M, int C, float slope,
+                     double* sums2, void* ws, int64_t ws_bytes, void* stream);
+/* dgamma[c] = sum g*xhat, dbeta[c] = sum g from the LOCAL sums2 (before any SyncBN all-reduce) */
+int vd_bn_param_grads(const double* sums2, int C, float* dgamma, float* dbeta, void* stream);
+/* backward, pass 2: dx = scale*(g - mean_g - xhat*mean_gx), means from (all-reduced) sums2 / count */
+int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift,
+                    const float* save_mean, const float* save_invstd,
+                    const double* sums2, double count, int64_t M, int C, float slope,
+                    float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pointwise helpers
+ * ------------------------------------------------------------------------------------- */
+/* out = a + b (residual backward fan-in etc.) */
+int vd_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int vd_fill(float* out, float v, int64_t n, void* stream);
+/* layers.py:11-20 _upsample (nearest x2) + yolo3.py:1170-1177 slice_like + concat(dim=1):
+ * out[n, y, x, 0:Cu) = up[n, y/2, x/2, :], out[..., Cu:Cu+Cr) = route[n, y, x, :] */
+int vd_upsample2x_concat(const float* up, const float* route, float* out,
+                         int N, int Ho, int Wo, int Cu, int Cr, void* stream);
+/* backward: dup[n,y2,x2,:] = sum of the 4 children of dout[..., 0:Cu); droute = dout[..., Cu:) */
+int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute,
+                             int N, int Ho, int Wo, int Cu, int Cr, void* stream);
+/* NCHW fp32 -> NHWC fp32 (the reference feeds NCHW, transforms.py:239-245) */
+int vd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, void* stream);
+/* transforms.py:229-245: uint8 HWC -> /255 -> (x-mean)/std, NHWC fp32 */
+int vd_preprocess_u8_nhwc(const uint8_t* in, float* out, int64_t npix, void* stream);
+/* layers.py:161-205 TemporalPooling over K frames: x [B,K,HW*C] -> y [B,HW*C]; type 0=max 1=mean */
+int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, int64_t inner, int type,
+                     void* stream);
+int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int B, int K,
+                         int64_t inner, int type, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * YOLO head: decode / filter / NMS / targets / loss
+ * Head tensors are the raw prediction-conv outputs, NHWC [B, g, g, ldh], channel = a*(5+C)+j,
+ * j: 0,1 = raw xy, 2,3 = raw wh, 4 = objectness, 5.. = classes (yolo3.py:158-165).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* head[3];   /* scale order = reference output order: stride 32, 16, 8 (yolo3.py:1013) */
+    int32_t g[3];           /* grid side per scale */
+    int32_t ldh;            /* channel pitch of head tensors */
+    float   stride[3];
+    float   anchors[3][6];  /* (w,h) x3 per scale, in reference output order */
+    int32_t B, C;
+} vd_head_desc;
+
+/* Inference (yolo3.py:167-199 + 1195-1206): fused decode + valid_thresh filter.
+ * Emits per image a candidate list of (score, row) where row is the row index into the
+ * (B, C*P, 6) tensor the reference would materialise.  counts[b] = number emitted (may exceed
+ * cap: then only the first cap are stored and vd_nms_topk reports overflow). */
+int vd_yolo_decode_filter(const vd_head_desc* h, float valid_thresh,
+                          float* cand_score, int32_t* cand_row, int32_t cap, int32_t* counts,
+                          void* stream);
+/* F.contrib.box_nms(overlap_thresh, topk, id_index=0, score_index=1, coord_start=2,
+ * force_suppress=False) + slice_axis(0:post_nms)  (yolo3.py:1197-1202).
+ * out_ids/out_scores [B,post_nms], out_boxes [B,post_nms,4], out_rows [B,post_nms] (original
+ * row index of each kept detection, -1 padded).  ws >= vd_nms_ws_bytes. */
+int64_t vd_nms_ws_bytes(int B, int cap, int topk);
+int vd_nms_topk(const vd_head_desc* h, const float* cand_score, const int32_t* cand_row,
+                int32_t cap, const int32_t* counts, float nms_thresh, int topk, int post_nms,
+                float* out_ids, float* out_scores, float* out_boxes, int32_t* out_rows,
+                void* ws, int64_t ws_bytes, void* stream);
+
+/* Training (yolo3.py:1140-1187 + yolo_target.py:173-281 + gluoncv YOLOV3Loss):
+ * fused decode -> dynamic ignore mask (IoU>thr vs gt) -> target merge -> 4 losses and their
+ * gradient wrt the raw head outputs.  targets are the prefetched ones, (B,P,.) in reference row
+ * order; gt [B,M,4] corner boxes padded with -1.  losses [B,4] = obj, center, scale, cls.
+ * dhead[s] has the geometry of head[s] (pad channels get 0).  box_out (optional) [B,P,4]. */
+int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M,
+                         const float* obj_t, const float* center_t, const float* scale_t,
+                         const float* weight_t, const float* class_t,
+                         float ignore_thresh, int label_smooth,
+                         float* losses, float* const dhead[3], float* box_out,
+                         void* ws, int64_t ws_bytes, void* stream);
+int64_t vd_yolo_loss_ws_bytes(const vd_head_desc* h);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser (gluon.Trainer('sgd'), train_yolov3.py:527-530,634):
+ *   g = rescale*grad ; mom = momentum*mom - lr*(g + wd*w) ; w += mom
+ * over a flat parameter arena.
+ * ------------------------------------------------------------------------------------- */
+int vd_sgd_momentum(float* w, const float* grad, float* mom, int64_t n,
+                    float lr, float momentum, float wd, float rescale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDDET_HIP_H */

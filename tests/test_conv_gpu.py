@@ -1,0 +1,199 @@
+"""GPU parity: tap-list implicit-GEMM conv (forward, data gradient, weight gradient, stem) vs the
+fp64 oracle (oracle/ops.py).  Tolerance 2e-4 abs on O(1) outputs (fp32 MFMA = exact fp32 fma chain)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as R
+from tests.util import dev, nchw_to_dev_nhwc, dev_nhwc_to_nchw, maxdiff
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _mk(n, ci, h, w, co, k, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, ci, h, w))
+    wt = rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)
+    return rng, x, wt
+
+
+def _packed(wt, co_pad):
+    from viddet_amd import ops
+    co, ci, kh, kw = wt.shape
+    wp = torch.empty(co_pad, kh * kw * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp, co_pad)
+    return wp
+
+
+FWD_CASES = [
+    # n, ci, h, w, co, k, stride, pad
+    (2, 32, 16, 16, 64, 3, 1, 1),
+    (2, 64, 13, 13, 32, 1, 1, 0),      # 128x32 tile
+    (1, 32, 20, 20, 64, 3, 2, 1),      # stride 2, 128x64 tile
+    (3, 128, 13, 13, 256, 3, 1, 1),    # 64x128 tile (few blocks)
+    (8, 64, 52, 52, 128, 3, 1, 1),     # 128x128 tile (many blocks)
+    (2, 96, 7, 9, 160, 1, 1, 0),       # ragged: Co not a tile multiple, odd spatial
+    (1, 64, 19, 19, 255, 1, 1, 0),     # head-like Co
+    (2, 32, 15, 17, 64, 3, 2, 1),      # stride 2 on odd sizes
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_conv_fwd_plain(case):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 1)
+    ref = R.conv2d(x, wt, s, p)
+    co_pad = ops.round_up(co, 32)
+    out = torch.full((n, ref.shape[2], ref.shape[3], co_pad), 7.0, device="cuda")
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co_pad), out, k=k, stride=s, pad=p, Co=co_pad, ldo=co_pad)
+    torch.cuda.synchronize()
+    got = dev_nhwc_to_nchw(out, co)
+    assert maxdiff(got, ref) < TOL
+    if co_pad > co:   # pad channels come out as exact zeros (zero weight rows)
+        assert float(out[..., co:].abs().max()) == 0.0
+
+
+def test_conv_fwd_epilogue_affine_leaky_residual():
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = 2, 64, 26, 26, 128, 3, 1, 1
+    rng, x, wt = _mk(n, ci, h, w, co, k, 2)
+    scale = rng.uniform(0.5, 1.5, co)
+    shift = rng.standard_normal(co)
+    res = rng.standard_normal((n, co, h, w))
+    z = R.conv2d(x, wt, s, p) * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    ref = R.leaky(z) + res
+    out = torch.empty(n, h, w, co, device="cuda")
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co), out, k=k, stride=s, pad=p, Co=co, scale=dev(scale),
+                 shift=dev(shift), residual=nchw_to_dev_nhwc(res), leaky=True)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out), ref) < TOL
+
+
+def test_conv_fwd_bias_only():
+    from viddet_amd import ops
+    n, ci, h, w, co, k = 2, 128, 13, 13, 75, 1
+    rng, x, wt = _mk(n, ci, h, w, co, k, 3)
+    bias = rng.standard_normal(co)
+    ref = R.conv2d(x, wt, 1, 0, bias)
+    co_pad = 96
+    bpad = np.zeros(co_pad); bpad[:co] = bias
+    out = torch.empty(n, h, w, co_pad, device="cuda")
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co_pad), out, k=k, stride=1, pad=0, Co=co_pad, shift=dev(bpad))
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL
+
+
+DGRAD_CASES = [
+    (2, 32, 16, 16, 64, 3, 1, 1),
+    (2, 64, 13, 13, 32, 1, 1, 0),
+    (2, 32, 20, 20, 64, 3, 2, 1),
+    (1, 64, 15, 17, 128, 3, 2, 1),
+    (2, 96, 9, 9, 75, 1, 1, 0),        # head-like: Co padded to 96 on the dZ side
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad(case):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 4)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = rng.standard_normal((n, co, ho, wo))
+    dx_ref, _ = R.conv2d_backward(x, wt, dy, s, p)
+    co_pad = ops.round_up(co, 32)
+    dz = nchw_to_dev_nhwc(dy, co_pad)
+    dx = torch.full((n, h, w, ci), 3.0, device="cuda")
+    wdev = dev(wt)
+    for plan in ops.dgrad_plans(k, p, s, h, w):
+        if not plan["taps"]:
+            # no tap reaches this parity class: gradient is zero there
+            dx[:, plan["py"]::s, plan["px"]::s, :] = 0
+            continue
+        wp = torch.empty(ci, len(plan["taps"]) * co_pad, device="cuda")
+        ops.pack_weight_dgrad(wdev, wp, Co=co, Co_pad=co_pad, Ci=ci, kd=1, kh=k, kw=k, tap_ids=plan["tap_ids"],
+                              src_packed=False)
+        ops.conv_igemm(dz, wp, dx, N=n, Hi=ho, Wi=wo, Ci=co_pad, Hg=plan["Hg"], Wg=plan["Wg"], in_stride=1,
+                       taps=plan["taps"], Ho=h, Wo=w, Co=ci, ldo=ci, out_stride=s, out_oy=plan["py"],
+                       out_ox=plan["px"])
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(dx), dx_ref) < TOL
+
+
+def test_conv_dgrad_accumulate_and_packed_source():
+    """dgrad from the fwd-packed weight layout, accumulating into an existing gradient."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = 2, 64, 12, 12, 128, 3, 1, 1
+    rng, x, wt = _mk(n, ci, h, w, co, k, 5)
+    dy = rng.standard_normal((n, co, h, w))
+    prev = rng.standard_normal((n, ci, h, w))
+    dx_ref, _ = R.conv2d_backward(x, wt, dy, s, p)
+    dx = nchw_to_dev_nhwc(prev)
+    wpf = _packed(wt, co)
+    plan = ops.dgrad_plans(k, p, s, h, w)[0]
+    wp = torch.empty(ci, len(plan["taps"]) * co, device="cuda")
+    ops.pack_weight_dgrad(wpf, wp, Co=co, Co_pad=co, Ci=ci, kd=1, kh=k, kw=k, tap_ids=plan["tap_ids"], src_packed=True)
+    ops.conv_igemm(nchw_to_dev_nhwc(dy), wp, dx, N=n, Hi=h, Wi=w, Ci=co, Hg=h, Wg=w, in_stride=1, taps=plan["taps"],
+                   Ho=h, Wo=w, Co=ci, ldo=ci, residual=dx, ldr=ci)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(dx), dx_ref + prev) < TOL
+
+
+WGRAD_CASES = [
+    (2, 32, 16, 16, 64, 3, 1, 1, 0),
+    (2, 64, 13, 13, 32, 1, 1, 0, 0),
+    (2, 32, 20, 20, 64, 3, 2, 1, 0),
+    (4, 128, 26, 26, 256, 3, 1, 1, 0),
+    (2, 160, 9, 11, 96, 1, 1, 0, 1),   # Ci, Co not multiples of 128; single split
+    (2, 64, 15, 17, 128, 3, 2, 1, 7),  # forced odd split count
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p, splits = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 6)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = rng.standard_normal((n, co, ho, wo))
+    _, dw_ref = R.conv2d_backward(x, wt, dy, s, p)
+    dwp = torch.empty(co, k * k * ci, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ops.conv_wgrad(nchw_to_dev_nhwc(x), nchw_to_dev_nhwc(dy), dwp, ws, k=k, stride=s, pad=p, Co=co, splits=splits)
+    dw = torch.empty(co, ci, k, k, device="cuda")
+    ops.unpack_weight(dwp, dw)
+    torch.cuda.synchronize()
+    scale = np.sqrt(n * ho * wo)
+    assert maxdiff(dw.cpu().numpy(), dw_ref) < TOL * scale
+
+
+def test_stem_im2col_conv_and_wgrad():
+    from viddet_amd import ops
+    n, h, w, co = 2, 24, 20, 32
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, 3, h, w))
+    wt = rng.standard_normal((co, 3, 3, 3)) / np.sqrt(27)
+    ref = R.conv2d(x, wt, 1, 1)
+    col = torch.empty(n, h, w, 32, device="cuda")
+    ops.stem_im2col(dev(x), col, nchw=True)
+    col2 = torch.empty(n, h, w, 32, device="cuda")
+    ops.stem_im2col(nchw_to_dev_nhwc(x), col2, nchw=False)
+    # stem weight as a 1x1 conv over the 32-wide im2col rows: wp[co][(ky*3+kx)*3+c]
+    wp_np = np.zeros((co, 32))
+    wp_np[:, :27] = wt.transpose(0, 2, 3, 1).reshape(co, 27)
+    wp = dev(wp_np)
+    out = torch.empty(n, h, w, co, device="cuda")
+    ops.conv_fwd(col, wp, out, k=1, stride=1, pad=0, Co=co)
+    torch.cuda.synchronize()
+    assert float((col - col2).abs().max()) == 0.0
+    assert maxdiff(dev_nhwc_to_nchw(out), ref) < TOL
+    dy = rng.standard_normal((n, co, h, w))
+    _, dw_ref = R.conv2d_backward(x, wt, dy, 1, 1)
+    dwp = torch.empty(co, 32, device="cuda")
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+    ops.conv_wgrad(col, nchw_to_dev_nhwc(dy), dwp, ws, k=1, stride=1, pad=0, Co=co)
+    torch.cuda.synchronize()
+    got = dwp.cpu().numpy()[:, :27].reshape(co, 3, 3, 3).transpose(0, 3, 1, 2)
+    assert maxdiff(got, dw_ref) < TOL * np.sqrt(n * h * w)
+    assert float(dwp[:, 27:].abs().max()) == 0.0

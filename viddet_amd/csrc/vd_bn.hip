@@ -1,0 +1,287 @@
+// vd_bn.hip — BatchNorm (training statistics, apply, backward) + LeakyReLU on NHWC [M, C] fp32.
+//
+// Replaces  norm_layer(epsilon=1e-5, momentum=0.9) + nn.LeakyReLU(0.1)   models/definitions/layers.py:68-69
+// (mxnet BatchNorm / gluon.contrib SyncBatchNorm, train_yolov3.py:347-354) and their backward.
+//
+// All kernels are HBM-bound streaming passes: float4 (16 B/lane) accesses, channel-contiguous, so a
+// wave covers 1 KiB of one pixel row run.  Per-channel reductions are two-level and deterministic:
+// fp32 per-thread partials over short runs -> LDS -> per-block rows in a workspace -> fp64 finalize.
+// The fp64 [2C] sums are the SyncBN exchange unit (one all-reduce per layer per direction).
+#include "vd_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+// MODE 0: a = x, b = x*x          (forward statistics)
+// MODE 1: a = g, b = g*xhat       (backward reductions), g = dy * leaky'(x*scale+shift)
+template <int MODE>
+__global__ __launch_bounds__(RED_THREADS) void k_bn_partial(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int64_t M,
+                                                            int C, float slope, float* __restrict__ part) {
+    __shared__ f32x4 sa[RED_THREADS], sb[RED_THREADS];
+    const int cvec = C >> 2;
+    const int cblk = cvec < RED_THREADS ? cvec : RED_THREADS;   // float4 columns handled per sweep
+    const int rl = RED_THREADS / cblk;                           // row lanes
+    const int tcol = threadIdx.x % cblk, trow = threadIdx.x / cblk;
+    const int64_t rows_per_blk = vd_cdiv(M, gridDim.x);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > M) r1 = M;
+    for (int cb = 0; cb < cvec; cb += cblk) {
+        const int col = cb + tcol;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (trow < rl && col < cvec) {
+            f32x4 sc, sh, mu, is;
+            if (MODE == 1) {
+                sc = reinterpret_cast<const f32x4*>(scale)[col];
+                sh = reinterpret_cast<const f32x4*>(shift)[col];
+                mu = reinterpret_cast<const f32x4*>(mean)[col];
+                is = reinterpret_cast<const f32x4*>(invstd)[col];
+            }
+            for (int64_t r = r0 + trow; r < r1; r += rl) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(x)[r * cvec + col];
+                if (MODE == 0) {
+                    a += v;
+                    b += v * v;
+                } else {
+                    const f32x4 d = reinterpret_cast<const f32x4*>(dy)[r * cvec + col];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = v[e] * sc[e] + sh[e];
+                        const float g = u > 0.f ? d[e] : d[e] * slope;
+                        a[e] += g;
+                        b[e] += g * (v[e] - mu[e]) * is[e];
+                    }
+                }
+            }
+        }
+        sa[threadIdx.x] = a;
+        sb[threadIdx.x] = b;
+        __syncthreads();
+        if (trow == 0 && col < cvec) {
+            for (int j = 1; j < rl; ++j) {
+                a += sa[j * cblk + tcol];
+                b += sb[j * cblk + tcol];
+            }
+            float* dst = part + (int64_t)blockIdx.x * 2 * C;
+            reinterpret_cast<f32x4*>(dst)[col] = a;
+            reinterpret_cast<f32x4*>(dst + C)[col] = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bn_sum_partials(const float* __restrict__ part, int nblk, int C2, double* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C2) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * C2 + i];
+    sums[i] = s;
+}
+
+__global__ void k_bn_finalize(const double* __restrict__ sums, double count, int C,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                              float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                              float* __restrict__ scale, float* __restrict__ shift,
+                              float* __restrict__ smean, float* __restrict__ sinv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;   // biased, as the reference normalises with
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma[c], b = beta[c];
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (smean) smean[c] = (float)mean;
+    if (sinv) sinv[c] = invstd;
+    if (rmean) rmean[c] = rmean[c] * momentum + (float)mean * (1.f - momentum);
+    if (rvar) rvar[c] = rvar[c] * momentum + (float)var * (1.f - momentum);
+}
+
+__global__ void k_bn_fold_eval(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                               int C, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+__global__ void k_bn_apply_leaky(const float* __restrict__ x, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, const float* __restrict__ res,
+                                 float* __restrict__ y, int64_t n4, int cvec, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % cvec);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = v[e] * sc[e] + sh[e];
+            o[e] = u > 0.f ? u : u * slope;
+        }
+        if (res) o += reinterpret_cast<const f32x4*>(res)[i];
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
+
+__global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                               const float* __restrict__ scale, const float* __restrict__ shift,
+                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                               const double* __restrict__ sums2, double count, int64_t n4, int C,
+                               float slope, float* __restrict__ dx) {
+    const int cvec = C >> 2;
+    const float inv_count = (float)(1.0 / count);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % cvec);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col];
+        const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[col];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = col * 4 + e;
+            const float mg = (float)sums2[c] * inv_count;
+            const float mgx = (float)sums2[C + c] * inv_count;
+            const float u = v[e] * sc[e] + sh[e];
+            const float g = u > 0.f ? d[e] : d[e] * slope;
+            const float xh = (v[e] - mu[e]) * is[e];
+            o[e] = sc[e] * (g - mg - xh * mgx);
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+__global__ void k_bn_param_grads(const double* __restrict__ sums2, int C, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums2[c];
+    dgamma[c] = (float)sums2[C + c];
+}
+
+int red_blocks(int64_t M) {
+    int64_t nb = vd_cdiv(M, 64);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+int stream_blocks(int64_t n) {
+    int64_t nb = vd_cdiv(n, 256);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t vd_bn_stats_ws_bytes(int64_t M, int C) { return (int64_t)red_blocks(M) * 2 * C * (int64_t)sizeof(float); }
+
+int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(x && sums && ws && M > 0 && C > 0 && C % 4 == 0, "vd_bn_stats: bad args (C=%d)", C);
+    VD_REQUIRE(C / 4 <= RED_THREADS ? (RED_THREADS % (C / 4) == 0) : ((C / 4) % RED_THREADS == 0),
+               "vd_bn_stats: C/4=%d must divide or be a multiple of %d", C / 4, RED_THREADS);
+    const int nb = red_blocks(M);
+    if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
+        vd_set_error("vd_bn_stats: workspace too small");
+        return VD_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_partial<0>, dim3(nb), dim3(RED_THREADS), 0, s, x, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, M, C, 0.f, (float*)ws);
+    VD_CHECK_LAUNCH("vd_bn_stats");
+    hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 256)), dim3(256), 0, s, (const float*)ws, nb,
+                       2 * C, sums);
+    VD_CHECK_LAUNCH("vd_bn_stats/sum");
+    return VD_OK;
+}
+
+int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, void* stream) {
+    VD_REQUIRE(sums && gamma && beta && scale && shift && count > 0 && C > 0, "vd_bn_finalize: bad args");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)vd_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count,
+                       C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    VD_CHECK_LAUNCH("vd_bn_finalize");
+    return VD_OK;
+}
+
+int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    float eps, int C, float* scale, float* shift, void* stream) {
+    VD_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "vd_bn_fold_eval: bad args");
+    hipLaunchKernelGGL(k_bn_fold_eval, dim3((unsigned)vd_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    VD_CHECK_LAUNCH("vd_bn_fold_eval");
+    return VD_OK;
+}
+
+int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                      int64_t M, int C, float slope, void* stream) {
+    VD_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && C % 4 == 0, "vd_bn_apply_leaky: bad args");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(k_bn_apply_leaky, dim3(stream_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       residual, y, n4, C / 4, slope);
+    VD_CHECK_LAUNCH("vd_bn_apply_leaky");
+    return VD_OK;
+}
+
+int vd_bn_bwd_reduce(const float* x, const float* dy, const float* scale, const float* shift,
+                     const float* save_mean, const float* save_invstd, int64_t M, int C, float slope,
+                     double* sums2, void* ws, int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && ws && M > 0 && C % 4 == 0,
+               "vd_bn_bwd_reduce: bad args");
+    VD_REQUIRE(C / 4 <= RED_THREADS ? (RED_THREADS % (C / 4) == 0) : ((C / 4) % RED_THREADS == 0),
+               "vd_bn_bwd_reduce: unsupported C=%d", C);
+    const int nb = red_blocks(M);
+    if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
+        vd_set_error("vd_bn_bwd_reduce: workspace too small");
+        return VD_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_partial<1>, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, scale, shift, save_mean, save_invstd,
+                       M, C, slope, (float*)ws);
+    VD_CHECK_LAUNCH("vd_bn_bwd_reduce");
+    hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 256)), dim3(256), 0, s, (const float*)ws, nb,
+                       2 * C, sums2);
+    VD_CHECK_LAUNCH("vd_bn_bwd_reduce/sum");
+    return VD_OK;
+}
+
+int vd_bn_param_grads(const double* sums2, int C, float* dgamma, float* dbeta, void* stream) {
+    VD_REQUIRE(sums2 && dgamma && dbeta && C > 0, "vd_bn_param_grads: bad args");
+    hipLaunchKernelGGL(k_bn_param_grads, dim3((unsigned)vd_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums2, C,
+                       dgamma, dbeta);
+    VD_CHECK_LAUNCH("vd_bn_param_grads");
+    return VD_OK;
+}
+
+int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift, const float* save_mean,
+                    const float* save_invstd, const double* sums2, double count, int64_t M, int C, float slope,
+                    float* dx, void* stream) {
+    VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && dx && count > 0 && C % 4 == 0,
+               "vd_bn_bwd_apply: bad args");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(stream_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
+                       save_mean, save_invstd, sums2, count, n4, C, slope, dx);
+    VD_CHECK_LAUNCH("vd_bn_bwd_apply");
+    return VD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,609 @@
+// vd_conv.hip — tap-list implicit-GEMM convolution for gfx950 on the exact-fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), plus its weight-gradient twin and the weight (un)packers.
+//
+// Replaces, on the reference side (paths under /root/reference):
+//   nn.Conv2D inside _conv2d                     models/definitions/layers.py:66-67
+//   nn.Conv2D prediction conv (with bias)        models/definitions/yolo/yolo3.py:62
+//   nn.Conv3D inside _conv3d / _conv21d          models/definitions/layers.py:73-89
+//   their autograd backward                      train_yolov3.py:631
+//
+// Data layout: activations NHWC fp32 (channel-contiguous => the GEMM K run of one tap is one
+// contiguous 128-B segment per pixel), weights packed [Co][T*Ci] (K-contiguous).
+//
+// GEMM view (forward / dgrad):  M = N*Hg*Wg pixels, N = Co, K = T*Ci.
+//   LDS tiles [rows][32+4] fp32: the +4 pad makes 16 rows that are distinct mod 16 hit 16
+//   distinct 4-bank slots, so every ds_read_b128 lane group is conflict free.
+//   MFMA operand map (guide §3): lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31].  Each lane
+//   reads 4 consecutive k (one ds_read_b128) at k0 = 8*kc + 4*(l>>5) and feeds them to 4 MFMAs;
+//   over (kc, half, j) every k of the 32-chunk is summed exactly once.
+//   C/D map: acc[r] -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31  => a store instruction writes two
+//   128-B row segments (channel-contiguous NHWC).
+#include "vd_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+struct RowInfo {
+    int pix;   // pixel index n*Hi*Wi + iy0*Wi + ix0 of tap (0,0,0); -1 if the row is out of range
+    int pk;    // iy0 | ix0<<12 | fz<<24
+};
+
+template <bool XF>
+__device__ __forceinline__ f32x4 load_a_chunk(const vd_conv_desc& p, const RowInfo ri, int dy, int dx,
+                                              int dz, int doff, int coff, const f32x4 sc,
+                                              const f32x4 sh) {
+    const int iy = (ri.pk & 0xfff) + dy;
+    const int ix = ((ri.pk >> 12) & 0xfff) + dx;
+    const int fz = ((ri.pk >> 24) & 0x7f) + dz;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ri.pix >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+        (unsigned)fz < (unsigned)p.Kfr) {
+        v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)(ri.pix + doff) * p.Ci + coff));
+        if (XF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] * sc[e] + sh[e];
+                v[e] = t > 0.f ? t : t * p.in_slope;
+            }
+        }
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, bool XF>
+__global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                        // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
+    const int ntile = (p.Co + BN - 1) / BN;
+    const int lid = vd_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % ntile, tile_m = lid / ntile;
+    const int Ktot = p.T * p.Ci;
+
+    const int lrow = tid >> 3;
+    const int lc4 = (tid & 7) * 4;
+
+    RowInfo ri[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int64_t m = (int64_t)tile_m * BM + lrow + 32 * i;
+        if (m < M) {
+            const int gx = (int)(m % p.Wg);
+            const int64_t t = m / p.Wg;
+            const int gy = (int)(t % p.Hg);
+            const int n = (int)(t / p.Hg);
+            const int iy0 = gy * p.in_stride, ix0 = gx * p.in_stride;
+            ri[i].pix = (n * p.Hi + iy0) * p.Wi + ix0;
+            ri[i].pk = iy0 | (ix0 << 12) | ((n % p.Kfr) << 24);
+        } else {
+            ri[i].pix = -1;
+            ri[i].pk = 0;
+        }
+    }
+    const float* bptr[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = tile_n * BN + lrow + 32 * i;
+        bptr[i] = (n < p.Co) ? p.wp + (int64_t)n * Ktot + lc4 : nullptr;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    f32x4 ra[AP], rb[BP];
+    int t_tap = 0, c0 = 0;   // k-step cursor of the NEXT tile to load
+
+    auto gload = [&]() {
+        const int dy = p.dy[t_tap], dx = p.dx[t_tap], dz = p.dz[t_tap];
+        const int doff = (dz * p.Hi + dy) * p.Wi + dx;
+        const int coff = c0 + lc4;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (XF) {
+            sc = *reinterpret_cast<const f32x4*>(p.in_scale + coff);
+            sh = *reinterpret_cast<const f32x4*>(p.in_shift + coff);
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) ra[i] = load_a_chunk<XF>(p, ri[i], dy, dx, dz, doff, coff, sc, sh);
+        const int koff = t_tap * p.Ci + c0;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (bptr[i]) v = *reinterpret_cast<const f32x4*>(bptr[i] + koff);
+            rb[i] = v;
+        }
+        c0 += BK;
+        if (c0 >= p.Ci) { c0 = 0; ++t_tap; }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<f32x4*>(a + (lrow + 32 * i) * LDS_LD + lc4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<f32x4*>(b + (lrow + 32 * i) * LDS_LD + lc4) = rb[i];
+    };
+    auto compute = [&](int buf) {
+        const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+        const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                fa[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * LDS_LD + kc * 8);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                fb[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_LD + kc * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j],
+                                                                           acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    const int nks = p.T * (p.Ci / BK);
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = (ks + 1 < nks);
+        if (more) gload();
+        compute(cur);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------
+    const bool direct = (p.out_stride == 1 && p.out_oy == 0 && p.out_ox == 0 && p.Ho == p.Hg &&
+                         p.Wo == p.Wg);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + (lane & 31);
+        const bool cok = col < p.Co;
+        float sc = 1.f, sh = 0.f;
+        if ((p.flags & VD_EPI_AFFINE) && cok) {
+            if (p.scale) sc = p.scale[col];
+            if (p.shift) sh = p.shift[col];
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) +
+                                  4 * (lane >> 5);
+                if (!cok || m >= M) continue;
+                int64_t opix = m;
+                if (!direct) {
+                    const int gx = (int)(m % p.Wg);
+                    const int64_t t = m / p.Wg;
+                    const int gy = (int)(t % p.Hg);
+                    const int64_t n = t / p.Hg;
+                    opix = (n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
+                }
+                float v = acc[mi][ni][r];
+                if (p.flags & VD_EPI_AFFINE) v = v * sc + sh;
+                if (p.flags & VD_EPI_LEAKY) v = v > 0.f ? v : v * p.slope;
+                if (p.flags & VD_EPI_RESIDUAL) v += p.residual[opix * p.ldr + col];
+                p.out[opix * p.ldo + col] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool XF>
+int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int lds = 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
+    static bool attr_done = false;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
+    const int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(256), lds, s, d);
+    return 0;
+}
+
+template <bool XF>
+int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
+    const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
+    if (d.Co <= 32) return launch_igemm<4, 1, 1, 1, XF>(d, s);          // 128 x 32
+    if (d.Co <= 64) return launch_igemm<2, 2, 2, 1, XF>(d, s);          // 128 x 64
+    // 128 x 128 unless that leaves most CUs idle
+    const int64_t blk128 = vd_cdiv(M, 128) * vd_cdiv(d.Co, 128);
+    if (blk128 < 384) return launch_igemm<2, 2, 1, 2, XF>(d, s);        //  64 x 128
+    return launch_igemm<2, 2, 2, 2, XF>(d, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  D[co][t*Ci+c] = sum_pix dout[pix][co] * in[pix shifted by tap t][c]
+//   GEMM rows = co, cols = c (inside one tap), reduction = pixels.  Both operands are
+//   channel-contiguous per pixel, so the LDS tiles are [pixel][128] and the MFMA operands are
+//   fetched with conflict-free ds_read_b32 (lane -> channel, half-wave -> pixel parity).
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_BM = 128, WG_BN = 128, WG_BP = 32;
+
+template <bool XF>
+__global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
+                                                    int splits, int64_t pix_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][WG_BP][WG_BM]   dout
+    float* Bs = smem + 2 * WG_BP * WG_BM;     // [2][WG_BP][WG_BN]   in
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ctiles = (p.Ci + WG_BN - 1) / WG_BN;
+    const int mtiles = (p.Co + WG_BM - 1) / WG_BM;
+    // block -> (split, tap, ctile, mtile)
+    int b = blockIdx.x;
+    const int tile_m = b % mtiles; b /= mtiles;
+    const int tile_c = b % ctiles; b /= ctiles;
+    const int tap = b % p.T;
+    const int split = b / p.T;
+    const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
+    const int64_t p_begin = (int64_t)split * pix_per_split;
+    int64_t p_end = p_begin + pix_per_split;
+    if (p_end > P) p_end = P;
+    const int Ktot = p.T * p.Ci;
+
+    const int dy = p.dy[tap], dx = p.dx[tap], dz = p.dz[tap];
+    const int doff = (dz * p.Hi + dy) * p.Wi + dx;
+
+    const int lpix = tid >> 5;          // 0..7 : pixel row inside a pass
+    const int lc = (tid & 31) * 4;      // channel offset inside the 128-wide tile
+    const int co = tile_m * WG_BM + lc;
+    const int ci = tile_c * WG_BN + lc;
+    const bool co_ok = co < p.Co;       // Co, Ci multiples of 4 => whole float4 in or out
+    const bool ci_ok = ci < p.Ci;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (XF && ci_ok) {
+        sc = *reinterpret_cast<const f32x4*>(p.in_scale + ci);
+        sh = *reinterpret_cast<const f32x4*>(p.in_shift + ci);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int64_t pbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pix = pbase + lpix + 8 * i;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (pix < p_end) {
+                if (co_ok) va = *reinterpret_cast<const f32x4*>(p.dout + pix * p.ldd + co);
+                if (ci_ok) {
+                    const int gx = (int)(pix % p.Wg);
+                    const int64_t t = pix / p.Wg;
+                    const int gy = (int)(t % p.Hg);
+                    const int n = (int)(t / p.Hg);
+                    const int iy = gy * p.in_stride + dy, ix = gx * p.in_stride + dx;
+                    const int fz = (n % p.Kfr) + dz;
+                    if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+                        (unsigned)fz < (unsigned)p.Kfr) {
+                        const int64_t ipix = ((int64_t)n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride + doff;
+                        vb = *reinterpret_cast<const f32x4*>(p.in + ipix * p.Ci + ci);
+                        if (XF) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float tt = vb[e] * sc[e] + sh[e];
+                                vb[e] = tt > 0.f ? tt : tt * p.in_slope;
+                            }
+                        }
+                    }
+                }
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * WG_BP * WG_BM;
+        float* bb = Bs + buf * WG_BP * WG_BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(a + (lpix + 8 * i) * WG_BM + lc) = ra[i];
+            *reinterpret_cast<f32x4*>(bb + (lpix + 8 * i) * WG_BN + lc) = rb[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* a = As + buf * WG_BP * WG_BM + (lane >> 5) * WG_BM + wm * 64 + (lane & 31);
+        const float* bb = Bs + buf * WG_BP * WG_BN + (lane >> 5) * WG_BN + wn * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < WG_BP / 2; ++kk) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[mi] = a[kk * 2 * WG_BM + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fb[ni] = bb[kk * 2 * WG_BN + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    const int64_t nsteps = (p_end > p_begin) ? vd_cdiv(p_end - p_begin, WG_BP) : 0;
+    if (nsteps > 0) {
+        gload(p_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int64_t ks = 0; ks < nsteps; ++ks) {
+        const int cur = (int)(ks & 1);
+        const bool more = ks + 1 < nsteps;
+        if (more) gload(p_begin + (ks + 1) * WG_BP);
+        compute(cur);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = dst + (int64_t)split * p.Co * Ktot;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int c = tile_c * WG_BN + wn * 64 + ni * 32 + (lane & 31);
+        if (c >= p.Ci) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tile_m * WG_BM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.Co) out[(int64_t)row * Ktot + tap * p.Ci + c] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__ dst, int64_t n4, int splits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws);
+    f32x4 a = src[i];
+    for (int s = 1; s < splits; ++s) {
+        const f32x4 v = src[(int64_t)s * n4 + i];
+        a += v;
+    }
+    reinterpret_cast<f32x4*>(dst)[i] = a;
+}
+
+int wgrad_pick_splits(const vd_wgrad_desc& d) {
+    if (d.splits > 0) return d.splits;
+    const int64_t P = (int64_t)d.N * d.Hg * d.Wg;
+    const int64_t tiles = vd_cdiv(d.Co, WG_BM) * vd_cdiv(d.Ci, WG_BN) * d.T;
+    int64_t s = vd_cdiv(1024, tiles);                 // aim at ~4 blocks per CU
+    const int64_t maxs = vd_cdiv(P, 8 * WG_BP);        // >= 8 k-steps per block
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 512) s = 512;
+    return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packers
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_fwd(const float* __restrict__ w, float* __restrict__ wp, int Co, int Co_pad,
+                           int Ci, int T) {
+    // wp[co][t*Ci + ci] = w[co][ci][t]   (w is OIHW / OIDHW, taps contiguous last)
+    const int64_t total = (int64_t)Co_pad * T * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ci);
+        const int64_t r = i / Ci;
+        const int t = (int)(r % T);
+        const int co = (int)(r / T);
+        wp[i] = (co < Co) ? w[((int64_t)co * Ci + ci) * T + t] : 0.f;
+    }
+}
+
+struct TapList { int v[VD_MAX_TAPS]; };
+
+__global__ void k_pack_dgrad(const float* __restrict__ w, float* __restrict__ wp, int Co, int Co_pad,
+                             int Ci, int T, const TapList taps, int ntaps, int src_packed) {
+    // wp[ci][j*Co_pad + co] = w[co][ci][taps[j]]   (w OIHW, or fwd-packed [co][t*Ci+ci] if src_packed)
+    const int64_t total = (int64_t)Ci * ntaps * Co_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co_pad);
+        const int64_t r = i / Co_pad;
+        const int j = (int)(r % ntaps);
+        const int ci = (int)(r / ntaps);
+        float v = 0.f;
+        if (co < Co)
+            v = src_packed ? w[((int64_t)co * T + taps.v[j]) * Ci + ci] : w[((int64_t)co * Ci + ci) * T + taps.v[j]];
+        wp[i] = v;
+    }
+}
+
+__global__ void k_unpack_wgrad(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int T) {
+    const int64_t total = (int64_t)Co * Ci * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const int64_t r = i / T;
+        const int ci = (int)(r % Ci);
+        const int co = (int)(r / Ci);
+        dw[i] = dwp[((int64_t)co * T + t) * Ci + ci];
+    }
+}
+
+// stem im2col: in [N,H,W,3] (nchw=0) or [N,3,H,W] (nchw=1) -> col [N,H,W,32],
+// col[.., (ky*3+kx)*3 + c] = in[y+ky-1][x+kx-1][c], zero padded, entries 27..31 = 0
+__global__ void k_stem_im2col(const float* __restrict__ in, float* __restrict__ col, int N, int H, int W,
+                              int nchw) {
+    const int64_t total = (int64_t)N * H * W * 8;   // one float4 of the 32-wide row per thread
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 7);
+        const int64_t pix = i >> 3;
+        const int x = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;
+            float val = 0.f;
+            if (k < 27) {
+                const int c = k % 3, tap = k / 3;
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    val = nchw ? in[(((int64_t)n * 3 + c) * H + iy) * W + ix]
+                               : in[(((int64_t)n * H + iy) * W + ix) * 3 + c];
+                }
+            }
+            v[e] = val;
+        }
+        reinterpret_cast<f32x4*>(col)[i] = v;
+    }
+}
+
+int check_taps(int T, const int32_t* dy, const int32_t* dx, int Hi, int Wi) {
+    if (T < 1 || T > VD_MAX_TAPS) return 0;
+    for (int t = 0; t < T; ++t)
+        if (dy[t] < -64 || dy[t] > 64 || dx[t] < -64 || dx[t] > 64) return 0;
+    return Hi < 4096 && Wi < 4096;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
+    VD_REQUIRE(d && d->in && d->wp && d->out, "vd_conv_igemm: null pointer");
+    VD_REQUIRE(d->Ci > 0 && d->Ci % 32 == 0, "vd_conv_igemm: Ci=%d must be a positive multiple of 32", d->Ci);
+    VD_REQUIRE(d->N > 0 && d->Hg > 0 && d->Wg > 0 && d->Co > 0, "vd_conv_igemm: bad shape");
+    VD_REQUIRE(check_taps(d->T, d->dy, d->dx, d->Hi, d->Wi), "vd_conv_igemm: bad tap list (T=%d)", d->T);
+    VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_igemm: bad Kfr=%d", d->Kfr);
+    VD_REQUIRE(d->ldo >= d->Co, "vd_conv_igemm: ldo < Co");
+    VD_REQUIRE((int64_t)d->N * d->Hi * d->Wi < (1ll << 31), "vd_conv_igemm: input pixel count overflows int32");
+    VD_REQUIRE((d->Hg - 1) * d->out_stride + d->out_oy < d->Ho && (d->Wg - 1) * d->out_stride + d->out_ox < d->Wo,
+               "vd_conv_igemm: output grid exceeds output tensor");
+    VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
+    VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->in_scale) dispatch_igemm<true>(*d, s);
+    else dispatch_igemm<false>(*d, s);
+    VD_CHECK_LAUNCH("vd_conv_igemm");
+    return VD_OK;
+}
+
+int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d) {
+    if (!d) return 0;
+    const int s = wgrad_pick_splits(*d);
+    return (s > 1) ? (int64_t)s * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
+}
+
+int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(d && d->in && d->dout && d->dwp, "vd_conv_wgrad: null pointer");
+    VD_REQUIRE(d->Ci > 0 && d->Ci % 4 == 0 && d->Co % 4 == 0, "vd_conv_wgrad: Ci=%d Co=%d must be multiples of 4", d->Ci, d->Co);
+    VD_REQUIRE(check_taps(d->T, d->dy, d->dx, d->Hi, d->Wi), "vd_conv_wgrad: bad tap list");
+    VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_wgrad: bad Kfr");
+    VD_REQUIRE(d->ldd >= d->Co && d->ldd % 4 == 0, "vd_conv_wgrad: bad ldd");
+    VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_wgrad: in_scale/in_shift mismatch");
+    const int splits = wgrad_pick_splits(*d);
+    const int64_t need = (splits > 1) ? (int64_t)splits * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
+    if (need > ws_bytes || (need > 0 && !ws)) {
+        vd_set_error("vd_conv_wgrad: workspace %lld < %lld", (long long)ws_bytes, (long long)need);
+        return VD_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t P = (int64_t)d->N * d->Hg * d->Wg;
+    int64_t pps = vd_cdiv(vd_cdiv(P, splits), WG_BP) * WG_BP;
+    const int64_t tiles = vd_cdiv(d->Co, WG_BM) * vd_cdiv(d->Ci, WG_BN) * d->T;
+    constexpr int lds = 2 * WG_BP * (WG_BM + WG_BN) * (int)sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    float* dst = (splits > 1) ? (float*)ws : d->dwp;
+    if (d->in_scale)
+        hipLaunchKernelGGL(k_conv_wgrad<true>, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, *d, dst, splits, pps);
+    else
+        hipLaunchKernelGGL(k_conv_wgrad<false>, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, *d, dst, splits, pps);
+    VD_CHECK_LAUNCH("vd_conv_wgrad");
+    if (splits > 1) {
+        const int64_t n4 = (int64_t)d->Co * d->T * d->Ci / 4;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)vd_cdiv(n4, 256)), dim3(256), 0, s, (const float*)ws, d->dwp, n4, splits);
+        VD_CHECK_LAUNCH("vd_conv_wgrad/reduce");
+    }
+    return VD_OK;
+}
+
+int vd_pack_weight_fwd(const float* w, float* wp, int Co, int Co_pad, int Ci, int kd, int kh, int kw, void* stream) {
+    VD_REQUIRE(w && wp && Co > 0 && Co_pad >= Co && Ci > 0, "vd_pack_weight_fwd: bad args");
+    const int T = kd * kh * kw;
+    const int64_t total = (int64_t)Co_pad * T * Ci;
+    const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_pack_fwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Co_pad, Ci, T);
+    VD_CHECK_LAUNCH("vd_pack_weight_fwd");
+    return VD_OK;
+}
+
+int vd_pack_weight_dgrad(const float* w, float* wp, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
+                         const int32_t* taps, int ntaps, int src_packed, void* stream) {
+    VD_REQUIRE(w && wp && taps && ntaps > 0 && ntaps <= VD_MAX_TAPS && Co_pad >= Co, "vd_pack_weight_dgrad: bad args");
+    const int T = kd * kh * kw;
+    TapList tl;
+    for (int j = 0; j < VD_MAX_TAPS; ++j) tl.v[j] = (j < ntaps) ? taps[j] : 0;
+    for (int j = 0; j < ntaps; ++j) VD_REQUIRE(taps[j] >= 0 && taps[j] < T, "vd_pack_weight_dgrad: tap index out of range");
+    const int64_t total = (int64_t)Ci * ntaps * Co_pad;
+    const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_pack_dgrad, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Co_pad, Ci, T, tl, ntaps, src_packed);
+    VD_CHECK_LAUNCH("vd_pack_weight_dgrad");
+    return VD_OK;
+}
+
+int vd_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int kd, int kh, int kw, void* stream) {
+    VD_REQUIRE(dwp && dw, "vd_unpack_wgrad: null");
+    const int T = kd * kh * kw;
+    const int64_t total = (int64_t)Co * Ci * T;
+    const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_unpack_wgrad, dim3(nb), dim3(256), 0, (hipStream_t)stream, dwp, dw, Co, Ci, T);
+    VD_CHECK_LAUNCH("vd_unpack_wgrad");
+    return VD_OK;
+}
+
+int vd_stem_im2col(const float* in, float* col, int N, int H, int W, int nchw, void* stream) {
+    VD_REQUIRE(in && col && N > 0 && H > 0 && W > 0, "vd_stem_im2col: bad args");
+    const int64_t total = (int64_t)N * H * W * 8;
+    const int nb = (int)(vd_cdiv(total, 256) < 8192 ? vd_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(k_stem_im2col, dim3(nb), dim3(256), 0, (hipStream_t)stream, in, col, N, H, W, nchw);
+    VD_CHECK_LAUNCH("vd_stem_im2col");
+    return VD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// vd_pointwise.hip — HBM-bound streaming kernels around the convolutions: residual fan-in add,
+// nearest-x2 upsample + channel concat (and backward), layout/normalisation of the input frames,
+// temporal pooling over the K frames of a window, and the SGD-momentum update.
+//
+// Reference call sites (under /root/reference):
+//   _upsample                      models/definitions/layers.py:11-20
+//   slice_like + concat            models/definitions/yolo/yolo3.py:1170-1177
+//   to_tensor / normalize          models/definitions/yolo/transforms.py:229-245 (mean/std :167-168)
+//   TemporalPooling                models/definitions/layers.py:161-205
+//   gluon.Trainer('sgd').step      train_yolov3.py:527-530,634
+//
+// All kernels move 16 B per lane (float4) with channel-contiguous NHWC addressing and a capped
+// grid-stride launch (<= 4096 blocks) so the 256 CUs stay saturated without launch overhead.
+#include "vd_common.h"
+
+namespace {
+
+inline int sblocks(int64_t n) {
+    int64_t nb = vd_cdiv(n, 256);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+#define GRID_STRIDE(i, n)                                                              \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);          \
+         i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n4,
+                      int64_t n) {
+    GRID_STRIDE(i, n4) {
+        reinterpret_cast<f32x4*>(o)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    }
+    // tail (n not a multiple of 4)
+    const int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) o[t] = a[t] + b[t];
+}
+
+__global__ void k_fill(float* __restrict__ o, float v, int64_t n) {
+    GRID_STRIDE(i, n) o[i] = v;
+}
+
+__global__ void k_upcat(const float* __restrict__ up, const float* __restrict__ route, float* __restrict__ out,
+                        int N, int Ho, int Wo, int Cu4, int Cr4) {
+    const int Ct4 = Cu4 + Cr4;
+    const int64_t total = (int64_t)N * Ho * Wo * Ct4;
+    const int Hu = Ho >> 1, Wu = Wo >> 1;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Ct4);
+        const int64_t pix = i / Ct4;
+        f32x4 v;
+        if (c < Cu4) {
+            const int x = (int)(pix % Wo);
+            const int64_t t = pix / Wo;
+            const int y = (int)(t % Ho);
+            const int64_t n = t / Ho;
+            v = reinterpret_cast<const f32x4*>(up)[((n * Hu + (y >> 1)) * Wu + (x >> 1)) * Cu4 + c];
+        } else {
+            v = reinterpret_cast<const f32x4*>(route)[pix * Cr4 + (c - Cu4)];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+__global__ void k_upcat_bwd_up(const float* __restrict__ dout, float* __restrict__ dup, int N, int Ho, int Wo,
+                               int Cu4, int Ct4) {
+    const int Hu = Ho >> 1, Wu = Wo >> 1;
+    const int64_t total = (int64_t)N * Hu * Wu * Cu4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cu4);
+        const int64_t pix = i / Cu4;
+        const int x = (int)(pix % Wu);
+        const int64_t t = pix / Wu;
+        const int y = (int)(t % Hu);
+        const int64_t n = t / Hu;
+        const int64_t base = ((n * Ho + 2 * y) * Wo + 2 * x);
+        const f32x4* d = reinterpret_cast<const f32x4*>(dout);
+        f32x4 s = d[base * Ct4 + c];
+        s += d[(base + 1) * Ct4 + c];
+        s += d[(base + Wo) * Ct4 + c];
+        s += d[(base + Wo + 1) * Ct4 + c];
+        reinterpret_cast<f32x4*>(dup)[i] = s;
+    }
+}
+
+__global__ void k_upcat_bwd_route(const float* __restrict__ dout, float* __restrict__ droute, int64_t npix,
+                                  int Cu4, int Cr4) {
+    const int Ct4 = Cu4 + Cr4;
+    const int64_t total = npix * Cr4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cr4);
+        const int64_t pix = i / Cr4;
+        reinterpret_cast<f32x4*>(droute)[i] = reinterpret_cast<const f32x4*>(dout)[pix * Ct4 + Cu4 + c];
+    }
+}
+
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const int64_t total = (int64_t)N * HW * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int hw = (int)(t % HW);
+        const int64_t n = t / HW;
+        out[i] = in[(n * C + c) * HW + hw];
+    }
+}
+
+__global__ void k_preprocess_u8(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    // mean/std of transforms.py:167-168; x/255 first (to_tensor), then (x-mean)/std (normalize)
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % 3);
+        out[i] = ((float)in[i] / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
+__global__ void k_tpool(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg, int B,
+                        int K, int64_t inner, int type) {
+    const int64_t total = (int64_t)B * inner;
+    GRID_STRIDE(i, total) {
+        const int64_t b = i / inner, r = i % inner;
+        const float* src = x + b * K * inner + r;
+        float v = src[0];
+        int am = 0;
+        if (type == 0) {
+            for (int k = 1; k < K; ++k) {
+                const float t = src[(int64_t)k * inner];
+                if (t > v) { v = t; am = k; }
+            }
+        } else {
+            for (int k = 1; k < K; ++k) v += src[(int64_t)k * inner];
+            v /= (float)K;
+        }
+        y[i] = v;
+        if (arg) arg[i] = am;
+    }
+}
+
+__global__ void k_tpool_bwd(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx,
+                            int B, int K, int64_t inner, int type) {
+    const int64_t total = (int64_t)B * K * inner;
+    GRID_STRIDE(i, total) {
+        const int64_t r = i % inner;
+        const int64_t t = i / inner;
+        const int k = (int)(t % K);
+        const int64_t b = t / K;
+        const float g = dy[b * inner + r];
+        dx[i] = (type == 0) ? (arg[b * inner + r] == k ? g : 0.f) : g / (float)K;
+    }
+}
+
+__global__ void k_sgd(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, int64_t n4,
+                      int64_t n, float lr, float mom, float wd, float rescale) {
+    GRID_STRIDE(i, n4) {
+        f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // mom = momentum*mom - lr*(rescale*grad + wd*w) ; w += mom   (mxnet sgd_mom_update)
+            mv[e] = mom * mv[e] - lr * (rescale * gv[e] + wd * wv[e]);
+            wv[e] += mv[e];
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(w)[i] = wv;
+    }
+    const int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float mv = mom * m[t] - lr * (rescale * g[t] + wd * w[t]);
+        m[t] = mv;
+        w[t] += mv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vd_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    VD_REQUIRE(a && b && out && n > 0, "vd_add: bad args");
+    hipLaunchKernelGGL(k_add, dim3(sblocks(n / 4 + 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, n);
+    VD_CHECK_LAUNCH("vd_add");
+    return VD_OK;
+}
+
+int vd_fill(float* out, float v, int64_t n, void* stream) {
+    VD_REQUIRE(out && n > 0, "vd_fill: bad args");
+    hipLaunchKernelGGL(k_fill, dim3(sblocks(n)), dim3(256), 0, (hipStream_t)stream, out, v, n);
+    VD_CHECK_LAUNCH("vd_fill");
+    return VD_OK;
+}
+
+int vd_upsample2x_concat(const float* up, const float* route, float* out, int N, int Ho, int Wo, int Cu, int Cr,
+                         void* stream) {
+    VD_REQUIRE(up && route && out && N > 0 && Ho % 2 == 0 && Wo % 2 == 0 && Cu % 4 == 0 && Cr % 4 == 0,
+               "vd_upsample2x_concat: bad args (Ho=%d Wo=%d Cu=%d Cr=%d)", Ho, Wo, Cu, Cr);
+    const int64_t total = (int64_t)N * Ho * Wo * ((Cu + Cr) / 4);
+    hipLaunchKernelGGL(k_upcat, dim3(sblocks(total)), dim3(256), 0, (hipStream_t)stream, up, route, out, N, Ho, Wo,
+                       Cu / 4, Cr / 4);
+    VD_CHECK_LAUNCH("vd_upsample2x_concat");
+    return VD_OK;
+}
+
+int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute, int N, int Ho, int Wo, int Cu, int Cr,
+                             void* stream) {
+    VD_REQUIRE(dout && dup && droute && N > 0 && Ho % 2 == 0 && Wo % 2 == 0 && Cu % 4 == 0 && Cr % 4 == 0,
+               "vd_upsample2x_concat_bwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t1 = (int64_t)N * (Ho / 2) * (Wo / 2) * (Cu / 4);
+    hipLaunchKernelGGL(k_upcat_bwd_up, dim3(sblocks(t1)), dim3(256), 0, s, dout, dup, N, Ho, Wo, Cu / 4, (Cu + Cr) / 4);
+    VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/up");
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    hipLaunchKernelGGL(k_upcat_bwd_route, dim3(sblocks(npix * (Cr / 4))), dim3(256), 0, s, dout, droute, npix, Cu / 4,
+                       Cr / 4);
+    VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/route");
+    return VD_OK;
+}
+
+int vd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, void* stream) {
+    VD_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "vd_nchw_to_nhwc: bad args");
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(sblocks(total)), dim3(256), 0, (hipStream_t)stream, in, out, N, C, H * W);
+    VD_CHECK_LAUNCH("vd_nchw_to_nhwc");
+    return VD_OK;
+}
+
+int vd_preprocess_u8_nhwc(const uint8_t* in, float* out, int64_t npix, void* stream) {
+    VD_REQUIRE(in && out && npix > 0, "vd_preprocess_u8_nhwc: bad args");
+    hipLaunchKernelGGL(k_preprocess_u8, dim3(sblocks(npix * 3)), dim3(256), 0, (hipStream_t)stream, in, out, npix * 3);
+    VD_CHECK_LAUNCH("vd_preprocess_u8_nhwc");
+    return VD_OK;
+}
+
+int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, int64_t inner, int type, void* stream) {
+    VD_REQUIRE(x && y && B > 0 && K > 0 && inner > 0 && (type == 0 || type == 1), "vd_temporal_pool: bad args");
+    hipLaunchKernelGGL(k_tpool, dim3(sblocks((int64_t)B * inner)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, K,
+                       inner, type);
+    VD_CHECK_LAUNCH("vd_temporal_pool");
+    return VD_OK;
+}
+
+int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int B, int K, int64_t inner, int type,
+                         void* stream) {
+    VD_REQUIRE(dy && dx && B > 0 && K > 0 && inner > 0 && (type == 1 || argmax), "vd_temporal_pool_bwd: bad args");
+    hipLaunchKernelGGL(k_tpool_bwd, dim3(sblocks((int64_t)B * K * inner)), dim3(256), 0, (hipStream_t)stream, dy, argmax,
+                       dx, B, K, inner, type);
+    VD_CHECK_LAUNCH("vd_temporal_pool_bwd");
+    return VD_OK;
+}
+
+int vd_sgd_momentum(float* w, const float* grad, float* mom, int64_t n, float lr, float momentum, float wd,
+                    float rescale, void* stream) {
+    VD_REQUIRE(w && grad && mom && n > 0, "vd_sgd_momentum: bad args");
+    hipLaunchKernelGGL(k_sgd, dim3(sblocks(n / 4 + 4)), dim3(256), 0, (hipStream_t)stream, w, grad, mom, n / 4, n, lr,
+                       momentum, wd, rescale);
+    VD_CHECK_LAUNCH("vd_sgd_momentum");
+    return VD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""ctypes binding of libviddet_hip.so (C-ABI declared in include/viddet_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this
+module raises.  Tensors are torch tensors used as storage only (``data_ptr()`` + current stream).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libviddet_hip.so")
+
+VD_MAX_TAPS = 27
+EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
+
+_fp = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_", _fp), ("wp", _fp), ("out", _fp), ("scale", _fp), ("shift", _fp), ("residual", _fp),
+        ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
+        ("Hg", C.c_int32), ("Wg", C.c_int32), ("in_stride", C.c_int32), ("T", C.c_int32),
+        ("dy", C.c_int32 * VD_MAX_TAPS), ("dx", C.c_int32 * VD_MAX_TAPS), ("dz", C.c_int32 * VD_MAX_TAPS),
+        ("Kfr", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
+        ("out_stride", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
+        ("ldo", C.c_int32), ("ldr", C.c_int32), ("flags", C.c_int32), ("slope", C.c_float),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("in_", _fp), ("dout", _fp), ("dwp", _fp),
+        ("N", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
+        ("Hg", C.c_int32), ("Wg", C.c_int32), ("Co", C.c_int32), ("ldd", C.c_int32),
+        ("in_stride", C.c_int32), ("T", C.c_int32),
+        ("dy", C.c_int32 * VD_MAX_TAPS), ("dx", C.c_int32 * VD_MAX_TAPS), ("dz", C.c_int32 * VD_MAX_TAPS),
+        ("Kfr", C.c_int32), ("splits", C.c_int32),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float),
+    ]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [
+        ("head", _fp * 3), ("g", C.c_int32 * 3), ("ldh", C.c_int32),
+        ("stride", C.c_float * 3), ("anchors", (C.c_float * 6) * 3),
+        ("B", C.c_int32), ("C", C.c_int32),
+    ]
+
+
+# every symbol include/viddet_hip.h declares, with its ctypes signature (restype, argtypes)
+_i, _i64, _f, _d, _p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
+SIGNATURES = {
+    "vd_last_error": (C.c_char_p, []),
+    "vd_version": (_i, []),
+    "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
+    "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
+    "vd_conv_wgrad": (_i, [C.POINTER(WgradDesc), _p, _i64, _p]),
+    "vd_stem_im2col": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vd_pack_weight_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vd_pack_weight_dgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _i, _p]),
+    "vd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vd_bn_stats_ws_bytes": (_i64, [_i64, _i]),
+    "vd_bn_stats": (_i, [_p, _i64, _i, _p, _p, _i64, _p]),
+    "vd_bn_finalize": (_i, [_p, _d, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "vd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "vd_bn_apply_leaky": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "vd_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),
+    "vd_bn_param_grads": (_i, [_p, _i, _p, _p, _p]),
+    "vd_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p]),
+    "vd_add": (_i, [_p, _p, _p, _i64, _p]),
+    "vd_fill": (_i, [_p, _f, _i64, _p]),
+    "vd_upsample2x_concat": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vd_upsample2x_concat_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vd_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vd_preprocess_u8_nhwc": (_i, [_p, _p, _i64, _p]),
+    "vd_temporal_pool": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vd_temporal_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vd_yolo_decode_filter": (_i, [C.POINTER(HeadDesc), _f, _p, _p, C.c_int32, _p, _p]),
+    "vd_nms_ws_bytes": (_i64, [_i, _i, _i]),
+    "vd_nms_topk": (_i, [C.POINTER(HeadDesc), _p, _p, C.c_int32, _p, _f, _i, _i, _p, _p, _p, _p, _p, _i64, _p]),
+    "vd_yolo_loss_ws_bytes": (_i64, [C.POINTER(HeadDesc)]),
+    "vd_yolo_loss_fwd_bwd": (_i, [C.POINTER(HeadDesc), _p, _i, _p, _p, _p, _p, _p, _f, _i, _p,
+                                  C.POINTER(_fp * 3), _p, _p, _i64, _p]),
+    "vd_sgd_momentum": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _p]),
+}
+
+_lib = None
+
+
+class VidDetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VidDetHipError(
+            "libviddet_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C viddet_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise VidDetHipError("%s failed (rc=%d): %s" % (what, rc, load().vd_last_error().decode()))
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream, as an integer (kernels are ordered on it)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

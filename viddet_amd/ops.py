@@ -1,0 +1,296 @@
+"""Thin operator layer over the C-ABI: builds descriptors (tap lists, geometry) for torch tensors
+used as device storage and launches the HIP kernels on torch's current stream.
+
+No arithmetic happens in Python/torch here; every function ends in a `lib.vd_*` call.
+Reference call sites are cited in include/viddet_hip.h next to each entry point.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, check, ptr
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _lib():
+    return L.load()
+
+
+def _s():
+    return L.stream_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+# tap lists
+# --------------------------------------------------------------------------------------------
+def fwd_taps(k, pad, kd=1, pad_d=0):
+    """Taps of a (kd,k,k) kernel in OI[D]HW order t = (kz*k + ky)*k + kx."""
+    taps = []
+    for kz in range(kd):
+        for ky in range(k):
+            for kx in range(k):
+                taps.append((ky - pad, kx - pad, kz - pad_d))
+    return taps
+
+
+def dgrad_plans(k, pad, stride, Hi, Wi, kd=1, pad_d=0):
+    """Data-gradient launches of a conv with kernel (kd,k,k), spatial `stride`, temporal stride 1.
+
+    Returns a list of plans; each plan = dict(py, px, Hg, Wg, taps=[(dy,dx,dz)], tap_ids=[t]) meaning:
+    dX[n, q_y*stride+py, q_x*stride+px, :] = sum_j dZ[n, q_y+dy_j, q_x+dx_j, frame+dz_j, :] . W[:, :, tap_ids[j]]
+    """
+    plans = []
+    for py in range(stride):
+        for px in range(stride):
+            Hg = (Hi - py + stride - 1) // stride
+            Wg = (Wi - px + stride - 1) // stride
+            if Hg <= 0 or Wg <= 0:
+                continue
+            taps, ids = [], []
+            for kz in range(kd):
+                for ky in range(k):
+                    if (py + pad - ky) % stride:
+                        continue
+                    for kx in range(k):
+                        if (px + pad - kx) % stride:
+                            continue
+                        taps.append(((py + pad - ky) // stride, (px + pad - kx) // stride, pad_d - kz))
+                        ids.append((kz * k + ky) * k + kx)
+            plans.append(dict(py=py, px=px, Hg=Hg, Wg=Wg, taps=taps, tap_ids=ids))
+    return plans
+
+
+def _set_taps(d, taps):
+    d.T = len(taps)
+    for i, (dy, dx, dz) in enumerate(taps):
+        d.dy[i], d.dx[i], d.dz[i] = dy, dx, dz
+
+
+# --------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------
+def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo,
+               out_stride=1, out_oy=0, out_ox=0, scale=None, shift=None, residual=None, ldr=0,
+               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1):
+    d = ConvDesc()
+    d.in_, d.wp, d.out = ptr(x), ptr(wp), ptr(out)
+    d.scale, d.shift, d.residual = ptr(scale), ptr(shift), ptr(residual)
+    d.N, d.Hi, d.Wi, d.Ci = N, Hi, Wi, Ci
+    d.Hg, d.Wg, d.in_stride = Hg, Wg, in_stride
+    _set_taps(d, taps)
+    d.Kfr = kfr
+    d.Ho, d.Wo, d.Co = Ho, Wo, Co
+    d.out_stride, d.out_oy, d.out_ox = out_stride, out_oy, out_ox
+    d.ldo, d.ldr = ldo, ldr
+    flags = 0
+    if scale is not None or shift is not None:
+        flags |= EPI_AFFINE
+    if leaky:
+        flags |= EPI_LEAKY
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+    d.flags, d.slope = flags, slope
+    d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
+    check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm")
+
+
+def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
+             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1):
+    """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo]."""
+    N, Hi, Wi, Ci = x.shape
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    ldo = Co if ldo is None else ldo
+    conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
+               taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
+               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr)
+    return Ho, Wo
+
+
+def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0):
+    """dwp [Co][T*Ci] (fwd-packed layout) = wgrad(x [N,Hi,Wi,Ci], dout [N,Ho,Wo,Co])."""
+    N, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, ldd = dout.shape
+    d = WgradDesc()
+    d.in_, d.dout, d.dwp = ptr(x), ptr(dout), ptr(dwp)
+    d.N, d.Hi, d.Wi, d.Ci = N, Hi, Wi, Ci
+    d.Hg, d.Wg, d.Co, d.ldd = Ho, Wo, Co, ldd
+    d.in_stride = stride
+    _set_taps(d, fwd_taps(k, pad, kd, pad_d))
+    d.Kfr, d.splits = kfr, splits
+    lib = _lib()
+    need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
+    if need > ws.numel() * ws.element_size():
+        raise L.VidDetHipError("conv_wgrad: workspace %d < %d bytes" % (ws.numel() * ws.element_size(), need))
+    check(lib.vd_conv_wgrad(C.byref(d), ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_conv_wgrad")
+
+
+def wgrad_ws_bytes(N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, kd=1, pad_d=0):
+    d = WgradDesc()
+    d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.Co, d.ldd = N, Hi, Wi, Ci, Ho, Wo, Co, Co
+    d.in_stride = stride
+    _set_taps(d, fwd_taps(k, pad, kd, pad_d))
+    d.Kfr, d.splits = 1, 0
+    return _lib().vd_conv_wgrad_ws_bytes(C.byref(d))
+
+
+def pack_weight_fwd(w_oihw, wp, Co_pad):
+    Co, Ci = w_oihw.shape[0], w_oihw.shape[1]
+    if w_oihw.dim() == 4:
+        kd, kh, kw = 1, w_oihw.shape[2], w_oihw.shape[3]
+    else:
+        kd, kh, kw = w_oihw.shape[2:]
+    check(_lib().vd_pack_weight_fwd(ptr(w_oihw), ptr(wp), Co, Co_pad, Ci, kd, kh, kw, _s()), "vd_pack_weight_fwd")
+
+
+def pack_weight_dgrad(w, wp, *, Co, Co_pad, Ci, kd, kh, kw, tap_ids, src_packed):
+    arr = (C.c_int32 * len(tap_ids))(*tap_ids)
+    check(_lib().vd_pack_weight_dgrad(ptr(w), ptr(wp), Co, Co_pad, Ci, kd, kh, kw, arr, len(tap_ids),
+                                      1 if src_packed else 0, _s()), "vd_pack_weight_dgrad")
+
+
+def unpack_weight(wp, w_oihw):
+    """fwd-packed [>=Co][T*Ci] -> OIHW (also used for gradients)."""
+    Co, Ci = w_oihw.shape[0], w_oihw.shape[1]
+    if w_oihw.dim() == 4:
+        kd, kh, kw = 1, w_oihw.shape[2], w_oihw.shape[3]
+    else:
+        kd, kh, kw = w_oihw.shape[2:]
+    check(_lib().vd_unpack_wgrad(ptr(wp), ptr(w_oihw), Co, Ci, kd, kh, kw, _s()), "vd_unpack_wgrad")
+
+
+def stem_im2col(x, col, nchw):
+    if nchw:
+        N, _, H, W = x.shape
+    else:
+        N, H, W, _ = x.shape
+    check(_lib().vd_stem_im2col(ptr(x), ptr(col), N, H, W, 1 if nchw else 0, _s()), "vd_stem_im2col")
+
+
+# --------------------------------------------------------------------------------------------
+# batch norm
+# --------------------------------------------------------------------------------------------
+def bn_stats(x2d_rows, C_, x, sums, ws):
+    check(_lib().vd_bn_stats(ptr(x), x2d_rows, C_, ptr(sums), ptr(ws), ws.numel() * ws.element_size(), _s()),
+          "vd_bn_stats")
+
+
+def bn_stats_ws_bytes(M, C_):
+    return _lib().vd_bn_stats_ws_bytes(M, C_)
+
+
+def bn_finalize(sums, count, C_, gamma, beta, eps, momentum, rmean, rvar, scale, shift, smean, sinv):
+    check(_lib().vd_bn_finalize(ptr(sums), float(count), C_, ptr(gamma), ptr(beta), eps, momentum, ptr(rmean),
+                                ptr(rvar), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), _s()), "vd_bn_finalize")
+
+
+def bn_fold_eval(gamma, beta, rmean, rvar, eps, scale, shift):
+    check(_lib().vd_bn_fold_eval(ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), eps, gamma.numel(), ptr(scale),
+                                 ptr(shift), _s()), "vd_bn_fold_eval")
+
+
+def bn_apply_leaky(x, scale, shift, residual, y, M, C_, slope=0.1):
+    check(_lib().vd_bn_apply_leaky(ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(y), M, C_, slope, _s()),
+          "vd_bn_apply_leaky")
+
+
+def bn_bwd_reduce(x, dy, scale, shift, smean, sinv, M, C_, sums2, ws, slope=0.1):
+    check(_lib().vd_bn_bwd_reduce(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), M, C_, slope,
+                                  ptr(sums2), ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_bn_bwd_reduce")
+
+
+def bn_param_grads(sums2, C_, dgamma, dbeta):
+    check(_lib().vd_bn_param_grads(ptr(sums2), C_, ptr(dgamma), ptr(dbeta), _s()), "vd_bn_param_grads")
+
+
+def bn_bwd_apply(x, dy, scale, shift, smean, sinv, sums2, count, M, C_, dx, slope=0.1):
+    check(_lib().vd_bn_bwd_apply(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), ptr(sums2),
+                                 float(count), M, C_, slope, ptr(dx), _s()), "vd_bn_bwd_apply")
+
+
+# --------------------------------------------------------------------------------------------
+# pointwise
+# --------------------------------------------------------------------------------------------
+def add(a, b, out):
+    check(_lib().vd_add(ptr(a), ptr(b), ptr(out), out.numel(), _s()), "vd_add")
+
+
+def fill(t, v):
+    check(_lib().vd_fill(ptr(t), float(v), t.numel(), _s()), "vd_fill")
+
+
+def upsample2x_concat(up, route, out):
+    N, Ho, Wo, Cr = route.shape
+    Cu = up.shape[3]
+    check(_lib().vd_upsample2x_concat(ptr(up), ptr(route), ptr(out), N, Ho, Wo, Cu, Cr, _s()), "vd_upsample2x_concat")
+
+
+def upsample2x_concat_bwd(dout, dup, droute):
+    N, Ho, Wo, Cr = droute.shape
+    Cu = dup.shape[3]
+    check(_lib().vd_upsample2x_concat_bwd(ptr(dout), ptr(dup), ptr(droute), N, Ho, Wo, Cu, Cr, _s()),
+          "vd_upsample2x_concat_bwd")
+
+
+def nchw_to_nhwc(x, out):
+    N, Cc, H, W = x.shape
+    check(_lib().vd_nchw_to_nhwc(ptr(x), ptr(out), N, Cc, H, W, _s()), "vd_nchw_to_nhwc")
+
+
+def preprocess_u8(x_u8, out):
+    check(_lib().vd_preprocess_u8_nhwc(ptr(x_u8), ptr(out), x_u8.numel() // 3, _s()), "vd_preprocess_u8_nhwc")
+
+
+def temporal_pool(x, y, argmax, B, K, inner, type_):
+    check(_lib().vd_temporal_pool(ptr(x), ptr(y), ptr(argmax), B, K, inner, type_, _s()), "vd_temporal_pool")
+
+
+def temporal_pool_bwd(dy, argmax, dx, B, K, inner, type_):
+    check(_lib().vd_temporal_pool_bwd(ptr(dy), ptr(argmax), ptr(dx), B, K, inner, type_, _s()), "vd_temporal_pool_bwd")
+
+
+def sgd_momentum(w, g, m, lr, momentum, wd, rescale):
+    check(_lib().vd_sgd_momentum(ptr(w), ptr(g), ptr(m), w.numel(), lr, momentum, wd, rescale, _s()), "vd_sgd_momentum")
+
+
+# --------------------------------------------------------------------------------------------
+# yolo head
+# --------------------------------------------------------------------------------------------
+def make_head_desc(heads, grids, ldh, strides, anchors, B, num_class):
+    h = HeadDesc()
+    for s in range(3):
+        h.head[s] = heads[s].data_ptr()
+        h.g[s] = grids[s]
+        h.stride[s] = float(strides[s])
+        for j in range(6):
+            h.anchors[s][j] = float(anchors[s][j])
+    h.ldh, h.B, h.C = ldh, B, num_class
+    return h
+
+
+def yolo_decode_filter(h, valid_thresh, cand_score, cand_row, cap, counts):
+    check(_lib().vd_yolo_decode_filter(C.byref(h), valid_thresh, ptr(cand_score), ptr(cand_row), cap, ptr(counts), _s()),
+          "vd_yolo_decode_filter")
+
+
+def nms_topk(h, cand_score, cand_row, cap, counts, nms_thresh, topk, post_nms, ids, scores, boxes, rows, ws):
+    check(_lib().vd_nms_topk(C.byref(h), ptr(cand_score), ptr(cand_row), cap, ptr(counts), nms_thresh, topk, post_nms,
+                             ptr(ids), ptr(scores), ptr(boxes), ptr(rows), ptr(ws), ws.numel() * ws.element_size(),
+                             _s()), "vd_nms_topk")
+
+
+def yolo_loss_fwd_bwd(h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh, label_smooth, losses,
+                      dheads, box_out, ws):
+    arr = (C.c_void_p * 3)(*[t.data_ptr() for t in dheads])
+    check(_lib().vd_yolo_loss_fwd_bwd(C.byref(h), ptr(gt), M, ptr(obj_t), ptr(center_t), ptr(scale_t), ptr(weight_t),
+                                      ptr(class_t), ignore_thresh, 1 if label_smooth else 0, ptr(losses),
+                                      C.byref(arr), ptr(box_out), ptr(ws), ws.numel() * ws.element_size(), _s()),
+          "vd_yolo_loss_fwd_bwd")
+
+
+def yolo_loss_ws_bytes(h):
+    return _lib().vd_yolo_loss_ws_bytes(C.byref(h))
