@@ -1,0 +1,221 @@
+"""CPU: sanity of the oracle itself.
+
+(i) INDEPENDENT CHECK (not the reference): the numpy oracle against torch-CPU float64 ops and torch
+    autograd on the same inputs — catches restatement / tape bugs.
+(ii) hand-computed known-answer tests for the semantics SURVEY.md Appendix A defines
+    (box_nms ties/thresholds, target assignment at cell borders, `break` on the first invalid gt, AP ladder).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import net as ON
+from oracle import ops as R
+from oracle import yolo as Y
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("k,s,p", [(1, 1, 0), (3, 1, 1), (3, 2, 1)])
+def test_conv_vs_torch(k, s, p):
+    rng = np.random.default_rng(0)
+    x, w = rng.standard_normal((2, 5, 9, 11)), rng.standard_normal((7, 5, k, k))
+    xt, wt = T(x).requires_grad_(), T(w).requires_grad_()
+    y = F.conv2d(xt, wt, stride=s, padding=p)
+    dy = rng.standard_normal(tuple(y.shape))
+    y.backward(T(dy))
+    assert np.allclose(R.conv2d(x, w, s, p), y.detach().numpy(), atol=1e-10)
+    dx, dw = R.conv2d_backward(x, w, dy, s, p)
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-10) and np.allclose(dw, wt.grad.numpy(), atol=1e-10)
+
+
+def test_conv3d_vs_torch():
+    rng = np.random.default_rng(1)
+    x, w = rng.standard_normal((2, 4, 3, 6, 6)), rng.standard_normal((5, 4, 3, 3, 3))
+    y = F.conv3d(T(x), T(w), padding=(1, 1, 1)).numpy()
+    assert np.allclose(R.conv3d(x, w, 1, 1), y, atol=1e-10)
+
+
+def test_bn_leaky_vs_torch():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 6, 5, 4)) * 2 + 1
+    g, b = rng.uniform(0.5, 1.5, 6), rng.standard_normal(6)
+    xt, gt, bt = T(x).requires_grad_(), T(g).requires_grad_(), T(b).requires_grad_()
+    rm, rv = torch.zeros(6, dtype=torch.float64), torch.ones(6, dtype=torch.float64)
+    u = F.batch_norm(xt, rm, rv, gt, bt, training=True, momentum=0.1, eps=1e-5)
+    y = F.leaky_relu(u, 0.1)
+    dy = rng.standard_normal(x.shape)
+    y.backward(T(dy))
+    uo, mean, var = R.bn_train(x, g, b)
+    assert np.allclose(R.leaky(uo), y.detach().numpy(), atol=1e-10)
+    dx, dg, db = R.bn_train_backward(x, g, mean, var, R.leaky_backward(uo, dy))
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-9)
+    assert np.allclose(dg, gt.grad.numpy(), atol=1e-9) and np.allclose(db, bt.grad.numpy(), atol=1e-9)
+    # running mean update: torch momentum 0.1 == reference momentum 0.9 ; torch's running_var is unbiased,
+    # the reference uses the biased batch variance -> checked against the definition directly
+    assert np.allclose(R.bn_running_update(np.zeros(6), mean), rm.numpy(), atol=1e-12)
+    assert np.allclose(var, x.var(axis=(0, 2, 3)), atol=1e-12)
+
+
+def _torch_net(P, c, x, train):
+    """Independent torch-CPU construction of the same architecture (autograd provides the backward)."""
+    tp = {k: T(v).clone().requires_grad_(not k.endswith(("running_mean", "running_var"))) for k, v in P.items()}
+
+    def cell(name, x, k, s, res=None):
+        z = F.conv2d(x, tp[name + ".0.weight"], stride=s, padding=k // 2)
+        u = F.batch_norm(z, tp[name + ".1.running_mean"].clone(), tp[name + ".1.running_var"].clone(),
+                         tp[name + ".1.gamma"], tp[name + ".1.beta"], training=train, momentum=0.1, eps=1e-5)
+        y = F.leaky_relu(u, 0.1)
+        return y if res is None else y + res
+
+    nm = ON.stage_names()
+    h = cell(nm(0), x, 3, 1)
+    f, routes = 1, []
+    for nl, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
+        h = cell(nm(f), h, 3, 2); f += 1
+        for _ in range(nl):
+            h = cell(nm(f) + ".body.1", cell(nm(f) + ".body.0", h, 1, 1), 3, 1, res=h); f += 1
+        if f in (15, 24, 29):
+            routes.append(h)
+    heads, h = [], routes[2]
+    for i in range(3):
+        for j in range(5):
+            h = cell("yolo_blocks.%d.body.%d" % (i, j), h, 1 if j % 2 == 0 else 3, 1)
+        tip = cell("yolo_blocks.%d.tip" % i, h, 3, 1)
+        heads.append(F.conv2d(tip, tp["yolo_outputs.%d.prediction.weight" % i], tp["yolo_outputs.%d.prediction.bias" % i]))
+        if i < 2:
+            t = cell("transitions.%d" % i, h, 1, 1)
+            h = torch.cat([F.interpolate(t, scale_factor=2, mode="nearest"), routes[1 - i]], dim=1)
+    return heads, tp
+
+
+def test_network_forward_backward_vs_torch_autograd():
+    c, b, size = 3, 2, 64
+    P = ON.init_params(c, seed=9, obj_bias=-1.0)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((b, 3, size, size))
+    gt = np.array([[[5., 8., 40., 50.], [-1, -1, -1, -1]], [[10., 12., 30., 28.], [20., 5., 60., 62.]]])
+    ids = np.array([[[1.], [-1.]], [[0.], [2.]]])
+    tg = Y.prefetch_targets(size, size, [2, 4, 8], gt, ids, c)
+    onet = ON.Net(P, c)
+    losses, G, heads = onet.train_step(x, gt, *tg)
+    # torch side: same heads -> same loss expressed with torch ops on the oracle's merged targets
+    th, tp = _torch_net(P, c, T(x), train=True)
+    for a, bb in zip(heads, th):
+        assert np.allclose(a, bb.detach().numpy(), atol=1e-8)
+    outs = [Y.yolo_output(h.detach().numpy(), c, Y.OUT_ANCHORS[s], Y.OUT_STRIDES[s], True) for s, h in enumerate(th)]
+    box = np.concatenate([o[0] for o in outs], axis=1)
+    merged = Y.merge_targets(box, gt, *tg, c, 0.7, False)
+    objness_t, center_t, scale_t, weight_t, class_t, class_mask = [T(m) for m in merged]
+    flat = [h.reshape(b, 3, 5 + c, -1).permute(0, 3, 1, 2).reshape(b, -1, 5 + c) for h in th]
+    p = torch.cat(flat, dim=1)
+    bce = lambda lg, z: F.binary_cross_entropy_with_logits(lg, z, reduction="none")
+    w = weight_t * objness_t
+    hard = torch.where(objness_t > 0, torch.ones_like(objness_t), objness_t)
+    om = torch.where(objness_t > 0, objness_t, (objness_t >= 0).double())
+    tot = (bce(p[..., 4:5], hard) * om).sum() + (bce(p[..., 0:2], center_t) * w).sum() + \
+          ((p[..., 2:4] - scale_t).abs() * w).sum() + (bce(p[..., 5:], class_t) * class_mask * objness_t).sum()
+    assert np.isclose(float(tot), float(sum(l.sum() for l in losses)), rtol=1e-10)
+    tot.backward()
+    for k, g in G.items():
+        assert np.allclose(g, tp[k].grad.numpy(), atol=1e-7 * max(1.0, np.abs(g).max())), k
+    # inference path equality too
+    ids_o, sc_o, bx_o, rows, heads_i = onet.detect(x)
+    th_i, _ = _torch_net(P, c, T(x), train=False)
+    for a, bb in zip(heads_i, th_i):
+        assert np.allclose(a, bb.detach().numpy(), atol=1e-8)
+
+
+# ---------------------------------------------------------------- known answers
+def test_box_nms_known_answer():
+    # rows: [id, score, x1,y1,x2,y2]
+    d = np.array([[
+        [0, 0.90, 0, 0, 10, 10],      # keep
+        [0, 0.80, 1, 1, 11, 11],      # IoU with row0 = 81/119 = 0.68 > 0.45 -> suppressed
+        [1, 0.85, 0, 0, 10, 10],      # other class: kept (force_suppress=False)
+        [0, 0.01, 50, 50, 60, 60],    # score == valid_thresh: NOT valid (strict >)
+        [0, 0.50, 0, 0, 10, 22.2222222],   # IoU with row0 = 100/222.2 = 0.45000000045 > 0.45 -> suppressed
+        [0, 0.40, 0, 0, 10, 22.3],    # IoU = 100/223 = 0.448 -> kept
+        [0, 0.30, 100, 100, 100, 120],  # zero area: union with itself... kept (IoU 0 with all)
+    ]])
+    out, kept = Y.box_nms(d, 0.45, 0.01, topk=400)
+    assert kept[0].tolist() == [0, 2, 5, 6]
+    assert np.all(out[0, 4:] == -1)
+    # topk truncation happens before suppression
+    out2, kept2 = Y.box_nms(d, 0.45, 0.01, topk=2)
+    assert kept2[0].tolist() == [0, 2]
+
+
+def test_yolo_output_row_order():
+    c, g = 2, 2
+    pred = np.zeros((1, 3 * (5 + c), g, g))
+    pred[0, 0 * 7 + 4] = 10.0           # anchor 0 objectness high everywhere
+    pred[0, 0 * 7 + 5 + 1, 1, 0] = 10.0  # class 1 at pixel (y=1,x=0), anchor 0
+    det = Y.yolo_output(pred, c, Y.OUT_ANCHORS[0], 32, training=False)
+    assert det.shape == (1, c * g * g * 3, 6)
+    row = 1 * (g * g * 3) + (1 * g + 0) * 3 + 0       # [class][pixel][anchor]
+    assert det[0, row, 0] == 1 and det[0, row, 1] > 0.99
+    cx, cy = (0.5 + 0) * 32, (0.5 + 1) * 32
+    aw, ah = Y.OUT_ANCHORS[0][0], Y.OUT_ANCHORS[0][1]
+    assert np.allclose(det[0, row, 2:], [cx - aw / 2, cy - ah / 2, cx + aw / 2, cy + ah / 2])
+
+
+def test_prefetch_targets_known_answer():
+    size, grids, c = 416, [13, 26, 52], 3
+    # a 100x80 box centred at (208, 104): best anchor by shape-IoU is (116,90) -> index 6 in OUT order = stride 32, a=0
+    gt = np.array([[[158., 64., 258., 144.], [-1, -1, -1, -1], [10., 10., 20., 23.]]])
+    ids = np.array([[[2.], [-1.], [1.]]])
+    obj, ctr, scl, wgt, cls = Y.prefetch_targets(size, size, grids, gt, ids, c)
+    P = 3 * (13 * 13 + 26 * 26 + 52 * 52)
+    assert obj.shape == (1, P, 1) and cls.shape == (1, P, 3)
+    # OUT_ANCHORS order: [116,90,156,198,373,326] first -> match index 0 -> layer 0 (stride 32), anchor 0
+    loc_x, loc_y = int(208 / 416 * 13), int(104 / 416 * 13)
+    p = (loc_y * 13 + loc_x) * 3 + 0
+    assert obj[0, p, 0] == 1 and obj.sum() == 1       # the third gt is never reached: loop BREAKS at the -1 row
+    assert np.allclose(ctr[0, p], [208 / 416 * 13 - loc_x, 104 / 416 * 13 - loc_y])
+    assert np.allclose(scl[0, p], [np.log(100 / 116), np.log(80 / 90)])
+    assert np.allclose(wgt[0, p], 2 - 100 * 80 / 416 / 416)
+    assert cls[0, p].tolist() == [0, 0, 1]
+    assert np.all(cls[0, np.arange(P) != p] == -1)
+
+
+def test_prefetch_targets_cell_border():
+    size, grids, c = 64, [2, 4, 8], 1
+    gt = np.array([[[24., 24., 40., 40.]]])     # centre exactly (32,32) = border of cells
+    obj, ctr, *_ = Y.prefetch_targets(size, size, grids, gt, np.zeros((1, 1, 1)), c)
+    p = int(np.nonzero(obj[0, :, 0])[0][0])
+    # 16x16 box -> best anchor (16,30)? shape-IoU: (10,13):130/256=.51 (16,30): 256/480=.53 (33,23): 256/759 -> (16,30) = stride 8, a=1
+    off = 3 * (2 * 2 + 4 * 4)
+    assert p == off + (4 * 8 + 4) * 3 + 1
+    assert np.allclose(ctr[0, p], [0.0, 0.0])
+
+
+def test_loss_ignore_and_masks():
+    # one prediction row per case: positive, negative, ignored
+    objness = np.array([[[0.3], [-0.2], [1.5]]])
+    obj_t = np.array([[[1.0], [0.0], [-1.0]]])
+    z2 = np.zeros((1, 3, 2)); zc = np.zeros((1, 3, 2))
+    cls_t = np.array([[[1., 0.], [-1., -1.], [-1., -1.]]])
+    mask = np.array([[[1., 1.], [0., 0.], [0., 0.]]])
+    w = np.array([[[1.5, 1.5], [0, 0], [0, 0]]])
+    (lo, lc, ls, lk), (go, gc, gs, gk) = Y.yolo3_loss(objness, z2 + 0.2, z2 + 0.5, zc + 0.1, obj_t, z2 + 0.25, z2 + 0.1,
+                                                       w, cls_t, mask, with_grads=True)
+    bce = lambda x, z: max(x, 0) - x * z + np.log1p(np.exp(-abs(x)))
+    assert np.isclose(lo[0], bce(0.3, 1) + bce(-0.2, 0))           # ignored row contributes nothing
+    assert np.isclose(lc[0], 2 * bce(0.2, 0.25) * 1.5) and np.isclose(ls[0], 2 * 0.4 * 1.5)
+    assert np.isclose(lk[0], bce(0.1, 1) + bce(0.1, 0))
+    assert go[0, 2, 0] == 0 and gk[0, 1].tolist() == [0, 0]
+
+
+def test_voc_map_ladder():
+    m = Y.VOCMApMetric(0.5, class_names=["a", "b"])
+    gtb = np.array([[0, 0, 10, 10], [20, 20, 30, 30], [40, 40, 50, 50]], dtype=float)
+    gtl = np.array([0, 0, 1])
+    pb = np.array([[0, 0, 10, 10], [100, 100, 110, 110], [20, 20, 30, 31], [40, 40, 50, 50], [0, 0, 10, 10.5]], dtype=float)
+    pl = np.array([0, 0, 0, 1, 0]); ps = np.array([0.9, 0.8, 0.7, 0.6, 0.5])
+    m.update([pb], [pl], [ps], [gtb], [gtl])
+    aps, mean = m.get()
+    # class a: matches by score: TP, FP, TP, (dup -> FP) ; recall ladder 1/2 @ p=1, 2/2 @ p=2/3 -> AP = .5*1 + .5*(2/3)
+    assert np.isclose(aps[0], 0.5 + 0.5 * (2 / 3)) and np.isclose(aps[1], 1.0)
+    assert np.isclose(mean, (aps[0] + 1.0) / 2)

@@ -1,0 +1,832 @@
+"""Host-side mirror of the reference's yolo3_darknet53 network object for the MI355X kernel library.
+
+Mirrors (paths under /root/reference):
+  yolo3_darknet53 factory            models/definitions/yolo/wrappers.py:9-110
+  Darknet-53 2-D backbone            models/definitions/darknet/three_darknet.py:100-123,152-264
+  YOLODetectionBlockV3               models/definitions/yolo/yolo3.py:218-263
+  YOLOOutputV3                       models/definitions/yolo/yolo3.py:43-199
+  YOLOV3T (wiring, NMS, losses)      models/definitions/yolo/yolo3.py:959-1302
+  _conv2d / _upsample                models/definitions/layers.py:11-20,63-70
+
+The network is a static list of nodes; for every (mode, batch, H, W) a *launch program* — a flat
+list of pre-built C-ABI calls (descriptor structs built once) — is compiled and replayed.  All
+arithmetic runs in libviddet_hip.so; torch provides device memory, streams and (for N>1 ranks)
+torch.distributed collectives only.  There is no autograd tape: the backward program is the fixed
+reverse schedule of this one graph.
+"""
+import ctypes as C
+import math
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+from .lib import ConvDesc, WgradDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL
+from .ops import round_up, fwd_taps, dgrad_plans
+
+# models/definitions/yolo/wrappers.py:80-84
+ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+STRIDES = [8, 16, 32]
+BN_EPS, BN_MOMENTUM, LEAKY_SLOPE = 1e-5, 0.9, 0.1   # layers.py:68-69
+
+
+class Slot:
+    """Late-bound pointer argument of a launch record (set right before a program runs)."""
+
+    def __init__(self):
+        self.value = None
+
+
+class Program:
+    """A flat replayable list of C-ABI launches; the stream is bound at run time (the last argument of
+    every vd_* entry point), so a program can be replayed eagerly or inside a HIP graph capture."""
+
+    def __init__(self):
+        self.recs = []
+        self.keep = []          # descriptor structs / tensors the records point into
+
+    def add(self, fname, *args):
+        fn = getattr(L.load(), fname)
+        self.recs.append((fname, fn, args))
+
+    def hold(self, *objs):
+        self.keep.extend(objs)
+
+    def run(self):
+        s = L.stream_ptr()
+        for fname, fn, args in self.recs:
+            a = [x.value if isinstance(x, Slot) else x for x in args]
+            rc = fn(*a, s)
+            if rc != 0:
+                L.check(rc, fname)
+
+
+class Parameter:
+    """Gluon-Parameter-like handle (name, shape in the reference's layout, wd_mult, grad_req)."""
+
+    def __init__(self, net, name, shape, kind, node=None, trainable=True):
+        self._net, self.name, self.shape, self.kind, self.node = net, name, tuple(shape), kind, node
+        self.wd_mult, self.lr_mult = 1.0, 1.0
+        self.grad_req = 'write' if trainable else 'null'
+        self.storage = None      # view into an arena (device layout)
+        self.grad_storage = None
+
+    # reference layout <-> device layout (conv weights are kept fwd-packed [Co_pad][T*Ci])
+    def data(self):
+        if self.kind == 'conv_weight':
+            out = torch.empty(self.shape, device=self.storage.device)
+            ops.unpack_weight(self.storage, out)
+            return out
+        if self.kind == 'stem_weight':
+            co = self.shape[0]
+            return self.storage.view(co, 32)[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        return self.storage[:int(np.prod(self.shape))].view(self.shape).clone()
+
+    def grad(self):
+        if self.kind == 'conv_weight':
+            out = torch.empty(self.shape, device=self.grad_storage.device)
+            ops.unpack_weight(self.grad_storage, out)
+            return out
+        if self.kind == 'stem_weight':
+            co = self.shape[0]
+            return self.grad_storage.view(co, 32)[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        return self.grad_storage[:int(np.prod(self.shape))].view(self.shape).clone()
+
+    def set_data(self, value):
+        v = torch.as_tensor(np.asarray(value.detach().cpu() if torch.is_tensor(value) else value), dtype=torch.float32)
+        assert tuple(v.shape) == self.shape, "%s: shape %s != %s" % (self.name, tuple(v.shape), self.shape)
+        v = v.to(self.storage.device).contiguous()
+        if self.kind == 'conv_weight':
+            co_pad = self.storage.numel() // (int(np.prod(self.shape[1:])))
+            ops.pack_weight_fwd(v, self.storage, co_pad)
+        elif self.kind == 'stem_weight':
+            co = self.shape[0]
+            tmp = torch.zeros(co, 32, device=v.device)
+            tmp[:, :27] = v.permute(0, 2, 3, 1).reshape(co, 27)
+            self.storage.copy_(tmp.view(-1))
+        else:
+            self.storage.zero_()
+            self.storage[:v.numel()].copy_(v.view(-1))
+        self._net._params_changed()
+
+
+class ParameterDict(OrderedDict):
+    def reset_ctx(self, ctx=None):     # train_yolov3.py:494 — parameters already live on this rank's GPU
+        return None
+
+    def select(self, pattern):
+        rx = re.compile(pattern)
+        out = ParameterDict()
+        for k, v in self.items():
+            if rx.match(k):
+                out[k] = v
+        return out
+
+
+class ConvNode:
+    def __init__(self, name, src, dst, cin, cout, k, stride, div_in, bn=True, residual=None, stem=False, head=False):
+        self.name, self.src, self.dst = name, src, dst
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.pad = k // 2
+        self.div_in = div_in                       # input spatial = H / div_in
+        self.div_out = div_in * stride
+        self.bn, self.residual, self.stem, self.head = bn, residual, stem, head
+        self.co_pad = round_up(cout, 32) if head else cout
+        self.ci_eff = 32 if stem else cin           # stem runs as 1x1 over the 32-wide im2col
+        self.T = 1 if stem else k * k
+
+
+class UpcatNode:
+    def __init__(self, name, up, route, dst, cu, cr, div_out):
+        self.name, self.up, self.route, self.dst, self.cu, self.cr, self.div_out = name, up, route, dst, cu, cr, div_out
+
+
+def _feature_name(f):
+    if f < 15:
+        return "stages.0.%d" % f
+    if f < 24:
+        return "stages.1.%d" % (f - 15)
+    return "stages.2.%d" % (f - 24)
+
+
+def build_graph(num_class):
+    """Node list of YOLOV3T(k=1) over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258)."""
+    nodes, tensors = [], OrderedDict()     # tensors[name] = (channels, div, pitch)
+
+    def T(name, c, div, ld=None):
+        tensors[name] = (c, div, c if ld is None else ld)
+        return name
+
+    T('in', 3, 1)
+    f = 0
+    cur = T('f0', 32, 1)
+    nodes.append(ConvNode(_feature_name(0), 'in', cur, 3, 32, 3, 1, 1, stem=True))
+    f = 1
+    div = 1
+    routes = []
+    for nlayer, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
+        nxt = T('f%d' % f, ch, div * 2)
+        nodes.append(ConvNode(_feature_name(f), cur, nxt, ch // 2, ch, 3, 2, div))
+        cur, div, f = nxt, div * 2, f + 1
+        for _ in range(nlayer):
+            mid = T('f%d.m' % f, ch // 2, div)
+            nxt = T('f%d' % f, ch, div)
+            nm = _feature_name(f)
+            nodes.append(ConvNode(nm + ".body.0", cur, mid, ch, ch // 2, 1, 1, div))
+            nodes.append(ConvNode(nm + ".body.1", mid, nxt, ch // 2, ch, 3, 1, div, residual=cur))
+            cur, f = nxt, f + 1
+        if f in (15, 24, 29):
+            routes.append(cur)
+    # neck + heads, deepest first (yolo3.py:1013-1054, 1126-1177)
+    A = 3 * (5 + num_class)
+    x, xc = routes[2], 1024
+    heads = []
+    for i, c in enumerate([512, 256, 128]):
+        d = 32 >> i
+        pre = "yolo_blocks.%d" % i
+        for j in range(5):
+            cout = c if j % 2 == 0 else 2 * c
+            k = 1 if j % 2 == 0 else 3
+            nxt = T('n%d.b%d' % (i, j), cout, d)
+            nodes.append(ConvNode("%s.body.%d" % (pre, j), x, nxt, xc, cout, k, 1, d))
+            x, xc = nxt, cout
+        route = x
+        tip = T('n%d.tip' % i, 2 * c, d)
+        nodes.append(ConvNode(pre + ".tip", route, tip, c, 2 * c, 3, 1, d))
+        hd = T('head%d' % i, A, d, round_up(A, 32))
+        nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, 2 * c, A, 1, 1, d, bn=False, head=True))
+        heads.append(hd)
+        if i < 2:
+            tr = T('n%d.tr' % i, c // 2, d)
+            nodes.append(ConvNode("transitions.%d" % i, route, tr, c, c // 2, 1, 1, d))
+            rt = routes[1 - i]
+            rc = tensors[rt][0]
+            cat = T('n%d.cat' % i, c // 2 + rc, d // 2)
+            nodes.append(UpcatNode("upcat.%d" % i, tr, rt, cat, c // 2, rc, d // 2))
+            x, xc = cat, c // 2 + rc
+    return nodes, tensors, heads
+
+
+class YOLOV3(object):
+    """The network object the reference's loops drive (net(x) / net(x, *targets), set_nms, reset_class,
+    collect_params, save/load_parameters, hybridize, initialize).  k=1 (YOLOV3T with k=1 == YOLOV3)."""
+
+    def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, ignore_iou_thresh=0.7,
+                 device="cuda", syncbn_scope=None, process_group=None):
+        self._classes = list(classes)
+        self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
+        self._ignore_iou_thresh = ignore_iou_thresh
+        self._label_smooth = False
+        self._target_generator = self            # train_yolov3.py:499-500 pokes net._target_generator._label_smooth
+        self.device = torch.device(device)
+        self.syncbn_scope = syncbn_scope         # None | 'reference' | 'all'
+        self.process_group = process_group
+        self._training = False
+        self._recording = False
+        self._programs = {}
+        self._fold_dirty = True
+        self._dgrad_dirty = True
+        self._graph_cache = {}
+        self.use_graphs = False
+        self._build(len(self._classes))
+
+    # ------------------------------------------------------------------ construction
+    def _build(self, num_class):
+        self.num_class = num_class
+        self.nodes, self.tensors, self.head_names = build_graph(num_class)
+        self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
+        # arena layout: [conv weights (fwd-packed) | bn gamma, beta, head bias]  -> wd / no_wd ranges
+        off = 0
+        for n in self.conv_nodes:
+            n.w_off = off
+            n.w_numel = n.co_pad * n.T * n.ci_eff
+            off += round_up(n.w_numel, 64)
+        self.n_weight = off
+        for n in self.conv_nodes:
+            if n.bn:
+                n.gamma_off, n.beta_off = off, off + round_up(n.cout, 64)
+                off += 2 * round_up(n.cout, 64)
+            else:
+                n.bias_off = off
+                off += round_up(n.co_pad, 64)
+        self.n_params = off
+        dev = self.device
+        self.weights = torch.zeros(off, device=dev)
+        self.grads = torch.zeros(off, device=dev)
+        self.momentum_buf = torch.zeros(off, device=dev)
+        soff = 0
+        for n in self.conv_nodes:
+            if n.bn:
+                n.stat_off = soff
+                soff += 2 * round_up(n.cout, 64)
+        self.running = torch.zeros(max(soff, 1), device=dev)
+        # per-node derived buffers: folded scale/shift (eval) and batch scale/shift/mean/invstd (train)
+        self.aux = torch.zeros(max(1, sum(6 * round_up(n.cout, 64) for n in self.conv_nodes if n.bn)), device=dev)
+        self.sums = torch.zeros(max(1, sum(4 * round_up(n.cout, 64) for n in self.conv_nodes)), dtype=torch.float64,
+                                device=dev)
+        aoff = doff = 0
+        for n in self.conv_nodes:
+            c64 = round_up(n.cout, 64)
+            if n.bn:
+                v = self.aux[aoff:aoff + 6 * c64]
+                n.fold_scale, n.fold_shift = v[0:n.cout], v[c64:c64 + n.cout]
+                n.b_scale, n.b_shift = v[2 * c64:2 * c64 + n.cout], v[3 * c64:3 * c64 + n.cout]
+                n.b_mean, n.b_invstd = v[4 * c64:4 * c64 + n.cout], v[5 * c64:5 * c64 + n.cout]
+                aoff += 6 * c64
+            n.sums = self.sums[doff:doff + 2 * c64]
+            n.sums2 = self.sums[doff + 2 * c64:doff + 4 * c64]
+            doff += 4 * c64
+        self._make_params()
+
+    def _make_params(self):
+        P = ParameterDict()
+
+        def reg(name, shape, kind, node, storage, gstorage, trainable=True):
+            p = Parameter(self, name, shape, kind, node, trainable)
+            p.storage, p.grad_storage = storage, gstorage
+            P[name] = p
+            return p
+
+        for n in self.conv_nodes:
+            wv = self.weights[n.w_off:n.w_off + n.w_numel]
+            gv = self.grads[n.w_off:n.w_off + n.w_numel]
+            n.wp, n.gwp = wv, gv
+            if n.head:
+                reg(n.name + ".weight", (n.cout, n.cin, 1, 1), 'conv_weight', n, wv, gv)
+                n.bias = self.weights[n.bias_off:n.bias_off + n.co_pad]
+                n.gbias = self.grads[n.bias_off:n.bias_off + n.co_pad]
+                reg(n.name + ".bias", (n.cout,), 'vector', n, n.bias, n.gbias)
+            else:
+                kind = 'stem_weight' if n.stem else 'conv_weight'
+                reg(n.name + ".0.weight", (n.cout, n.cin, n.k, n.k), kind, n, wv, gv)
+                n.gamma = self.weights[n.gamma_off:n.gamma_off + n.cout]
+                n.beta = self.weights[n.beta_off:n.beta_off + n.cout]
+                n.ggamma = self.grads[n.gamma_off:n.gamma_off + n.cout]
+                n.gbeta = self.grads[n.beta_off:n.beta_off + n.cout]
+                c64 = round_up(n.cout, 64)
+                n.rmean = self.running[n.stat_off:n.stat_off + n.cout]
+                n.rvar = self.running[n.stat_off + c64:n.stat_off + c64 + n.cout]
+                reg(n.name + ".1.gamma", (n.cout,), 'vector', n, n.gamma, n.ggamma)
+                reg(n.name + ".1.beta", (n.cout,), 'vector', n, n.beta, n.gbeta)
+                reg(n.name + ".1.running_mean", (n.cout,), 'vector', n, n.rmean, None, trainable=False)
+                reg(n.name + ".1.running_var", (n.cout,), 'vector', n, n.rvar, None, trainable=False)
+        self._params = P
+
+    # ------------------------------------------------------------------ reference-style surface
+    @property
+    def classes(self):
+        return self._classes
+
+    def collect_params(self, select=None):
+        return self._params if select is None else self._params.select(select)
+
+    def hybridize(self, active=True):
+        """The reference compiles a CachedOp here (train_yolov3.py:586); programs are always pre-compiled."""
+        return None
+
+    def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
+        # yolo3.py:1208-1228
+        self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
+        self._programs = {k: v for k, v in self._programs.items() if k[0] != 'infer'}
+        self._graph_cache.clear()
+
+    def initialize(self, init='uniform', seed=233, obj_bias=0.0):
+        """'uniform': MXNet default Uniform(0.07) for conv weights, gamma=1, beta=0, bias=0, running mean 0 / var 1.
+        'he': N(0, 2/(k*k*Cin)) conv weights (keeps synthetic activations O(1))."""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        for name, p in self._params.items():
+            if name.endswith('weight'):
+                if init == 'uniform':
+                    v = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.07
+                else:
+                    fan = p.shape[1] * p.shape[2] * p.shape[3]
+                    v = torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan)
+                p.set_data(v)
+            elif name.endswith('gamma') or name.endswith('running_var'):
+                p.set_data(torch.ones(p.shape))
+            elif name.endswith('bias'):
+                v = torch.zeros(p.shape)
+                if obj_bias != 0.0:
+                    v.view(3, -1)[:, 4] = obj_bias
+                p.set_data(v)
+            else:
+                p.set_data(torch.zeros(p.shape))
+        self.momentum_buf.zero_()
+        self.grads.zero_()
+
+    def reset_class(self, classes, reuse_weights=None):
+        """yolo3.py:1230-1302 + YOLOOutputV3.reset_class :76-129: rebuild the 3 prediction convs."""
+        old_classes, old = self._classes, {k: p.data().cpu() for k, p in self._params.items()}
+        old_npred = 5 + len(old_classes)
+        if isinstance(reuse_weights, (dict, list)):
+            if isinstance(reuse_weights, dict):
+                m = {}
+                for k, v in reuse_weights.items():
+                    if isinstance(v, str):
+                        if v not in old_classes:
+                            raise ValueError("{} not found in old class names {}".format(v, old_classes))
+                        v = old_classes.index(v)
+                    elif v < 0 or v >= len(old_classes):
+                        raise ValueError("Index {} out of bounds for old class names".format(v))
+                    if isinstance(k, str):
+                        if k not in classes:
+                            raise ValueError("{} not found in new class names {}".format(k, classes))
+                        k = list(classes).index(k)
+                    elif k < 0 or k >= len(classes):
+                        raise ValueError("Index {} out of bounds for new class names".format(k))
+                    m[k] = v
+                reuse_weights = m
+            else:
+                reuse_weights = {list(classes).index(x): old_classes.index(x) for x in reuse_weights
+                                 if x in classes and x in old_classes}
+        self._classes = list(classes)
+        self._programs.clear()
+        self._graph_cache.clear()
+        self._build(len(self._classes))
+        new_npred = 5 + len(self._classes)
+        g = torch.Generator(device='cpu').manual_seed(233)
+        for name, p in self._params.items():
+            if "yolo_outputs" not in name:
+                p.set_data(old[name])
+                continue
+            new = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.07 if name.endswith('weight') else torch.zeros(p.shape)
+            if reuse_weights:
+                od = old[name]
+                for k, v in reuse_weights.items():
+                    for a in range(3):
+                        new[5 + k + a * new_npred] = od[5 + v + a * old_npred]
+                        new[a * new_npred:a * new_npred + 5] = od[a * old_npred:a * old_npred + 5]
+            p.set_data(new)
+
+    def _params_changed(self):
+        self._fold_dirty = True
+        self._dgrad_dirty = True
+
+    # ------------------------------------------------------------------ buffers
+    def _buffers(self, key, B, H, W, train):
+        ck = ('buf', B, H, W, train)
+        if ck in self._programs:
+            return self._programs[ck]
+        dev = self.device
+        bufs = {}
+        for name, (c, div, ld) in self.tensors.items():
+            if name == 'in':
+                bufs['in'] = torch.empty(B, 3, H, W, device=dev)
+                continue
+            bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
+        bufs['col'] = torch.empty(B, H, W, 32, device=dev)
+        if train:
+            for n in self.conv_nodes:
+                if n.bn:
+                    bufs['z:' + n.dst] = torch.empty_like(bufs[n.dst])
+            for name in self.tensors:
+                if name != 'in':
+                    bufs['d:' + name] = torch.empty_like(bufs[name])
+            mx = max(bufs[n.dst].numel() for n in self.conv_nodes)
+            bufs['dz'] = torch.empty(mx, device=dev)
+            bufs['tmp'] = torch.empty(mx, device=dev)
+        self._programs[ck] = bufs
+        return bufs
+
+    def _grid(self, H, W):
+        assert H == W, "square inputs only (the reference resizes to data_shape x data_shape)"
+        assert H % 32 == 0, "input side must be a multiple of 32"
+        return [H // 32, H // 16, H // 8]
+
+    # ------------------------------------------------------------------ program builders
+    def _conv_desc(self, n, bufs, B, H, W, out, *, scale=None, shift=None, residual=None, leaky=False):
+        d = ConvDesc()
+        x = bufs['col'] if n.stem else bufs[n.src]
+        Hi, Wi = H // n.div_in, W // n.div_in
+        Ho, Wo = H // n.div_out, W // n.div_out
+        d.in_, d.wp, d.out = x.data_ptr(), n.wp.data_ptr(), out.data_ptr()
+        d.N, d.Hi, d.Wi, d.Ci = B, Hi, Wi, n.ci_eff
+        d.Hg, d.Wg, d.in_stride = Ho, Wo, n.stride
+        taps = [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad)
+        ops._set_taps(d, taps)
+        d.Kfr = 1
+        d.Ho, d.Wo, d.Co = Ho, Wo, n.co_pad
+        d.out_stride, d.out_oy, d.out_ox = 1, 0, 0
+        d.ldo = d.ldr = n.co_pad
+        flags = 0
+        if scale is not None or shift is not None:
+            flags |= EPI_AFFINE
+            d.scale = scale.data_ptr() if scale is not None else None
+            d.shift = shift.data_ptr() if shift is not None else None
+        if leaky:
+            flags |= EPI_LEAKY
+        if residual is not None:
+            flags |= EPI_RESIDUAL
+            d.residual = residual.data_ptr()
+        d.flags, d.slope = flags, LEAKY_SLOPE
+        return d
+
+    def _build_infer(self, B, H, W):
+        bufs = self._buffers('infer', B, H, W, False)
+        prog = Program()
+        prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
+        for n in self.nodes:
+            if isinstance(n, UpcatNode):
+                o = bufs[n.dst]
+                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
+                         o.shape[1], o.shape[2], n.cu, n.cr)
+                continue
+            if n.head:
+                d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
+            else:
+                res = bufs[n.residual] if n.residual else None
+                d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
+                                    leaky=True)
+            prog.hold(d)
+            prog.add('vd_conv_igemm', C.byref(d))
+        grids = self._grid(H, W)
+        hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
+                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+        P = 3 * sum(g * g for g in grids)
+        cap = min(self.num_class * P, 1 << 18)
+        o = dict(cand_score=torch.empty(B, cap, device=self.device),
+                 cand_row=torch.empty(B, cap, dtype=torch.int32, device=self.device),
+                 counts=torch.zeros(B, dtype=torch.int32, device=self.device),
+                 ids=torch.empty(B, self.post_nms, 1, device=self.device),
+                 scores=torch.empty(B, self.post_nms, 1, device=self.device),
+                 bboxes=torch.empty(B, self.post_nms, 4, device=self.device),
+                 rows=torch.empty(B, self.post_nms, dtype=torch.int32, device=self.device),
+                 overflow=torch.zeros(B, dtype=torch.int32, device=self.device))
+        prog.hold(hd, o)
+        prog.add('vd_yolo_decode_filter', C.byref(hd), 0.01, o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
+                 o['counts'].data_ptr())
+        prog.add('vd_nms_topk', C.byref(hd), o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
+                 o['counts'].data_ptr(), float(self.nms_thresh), int(self.nms_topk), int(self.post_nms),
+                 o['ids'].data_ptr(), o['scores'].data_ptr(), o['bboxes'].data_ptr(), o['rows'].data_ptr(),
+                 o['overflow'].data_ptr(), 4 * B)
+        return prog, bufs, o
+
+    def _refresh_fold(self):
+        if not self._fold_dirty:
+            return
+        for n in self.conv_nodes:
+            if n.bn:
+                ops.bn_fold_eval(n.gamma, n.beta, n.rmean, n.rvar, BN_EPS, n.fold_scale, n.fold_shift)
+        self._fold_dirty = False
+
+    # ------------------------------------------------------------------ inference
+    def _forward_infer(self, x):
+        B, _, H, W = x.shape
+        assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
+        key = ('infer', B, H, W)
+        if key not in self._programs:
+            self._programs[key] = self._build_infer(B, H, W)
+        prog, bufs, o = self._programs[key]
+        self._refresh_fold()
+        bufs['in'].copy_(x)
+        if self.use_graphs:
+            g = self._graph_cache.get(key)
+            if g is None:
+                prog.run()                       # warm-up outside capture (function attributes etc.)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    prog.run()
+                self._graph_cache[key] = g
+            g.replay()
+        else:
+            prog.run()
+        self.last_rows, self.last_overflow = o['rows'], o['overflow']
+        return o['ids'], o['scores'], o['bboxes']
+
+    # ------------------------------------------------------------------ training forward / backward
+    def _syncbn(self, n):
+        if not self.syncbn_scope or not torch.distributed.is_available() or not torch.distributed.is_initialized():
+            return False
+        if torch.distributed.get_world_size(self.process_group) < 2:
+            return False
+        if self.syncbn_scope == 'all':
+            return True
+        # 'reference': --syncbn only reaches the stem and the 5 stride-2 convs
+        return n.stem or n.stride == 2
+
+    def _build_train(self, B, H, W):
+        bufs = self._buffers('train', B, H, W, True)
+        dev = self.device
+        ws_bytes = 1 << 20
+        for n in self.conv_nodes:
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            if n.stem:
+                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B, Hi, Wi, 32, Ho, Wo, n.co_pad, 1, 1, 0))
+            else:
+                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.k, n.stride, n.pad))
+            ws_bytes = max(ws_bytes, ops.bn_stats_ws_bytes(B * Ho * Wo, n.co_pad))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(self.process_group)
+
+        # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
+        fwd, seg = [], Program()
+        seg.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
+
+        def cut(segments, p, fn):
+            segments.append(p)
+            segments.append(fn)
+            return Program()
+
+        for n in self.nodes:
+            if isinstance(n, UpcatNode):
+                o = bufs[n.dst]
+                seg.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B, o.shape[1],
+                        o.shape[2], n.cu, n.cr)
+                continue
+            Ho, Wo = H // n.div_out, W // n.div_out
+            M = B * Ho * Wo
+            if n.head:
+                d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
+                seg.hold(d)
+                seg.add('vd_conv_igemm', C.byref(d))
+                continue
+            z = bufs['z:' + n.dst]
+            d = self._conv_desc(n, bufs, B, H, W, z)
+            seg.hold(d)
+            seg.add('vd_conv_igemm', C.byref(d))
+            seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+            count = float(M)
+            if self._syncbn(n):
+                sums = n.sums
+                seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
+                count = float(M * world)
+            seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, n.gamma.data_ptr(), n.beta.data_ptr(), BN_EPS,
+                    BN_MOMENTUM, n.rmean.data_ptr(), n.rvar.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                    n.b_mean.data_ptr(), n.b_invstd.data_ptr())
+            res = bufs[n.residual].data_ptr() if n.residual else None
+            seg.add('vd_bn_apply_leaky', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
+                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE)
+        # loss (targets are late-bound)
+        grids = self._grid(H, W)
+        hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
+                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+        slots = dict(gt=Slot(), M=Slot(), obj=Slot(), ctr=Slot(), scl=Slot(), wgt=Slot(), cls=Slot(), smooth=Slot())
+        losses = torch.zeros(B, 4, device=dev)
+        dh = (C.c_void_p * 3)(*[bufs['d:' + h].data_ptr() for h in self.head_names])
+        lws = torch.empty(max(16, ops.yolo_loss_ws_bytes(hd)), dtype=torch.uint8, device=dev)
+        seg.hold(hd, dh, lws)
+        seg.add('vd_yolo_loss_fwd_bwd', C.byref(hd), slots['gt'], slots['M'], slots['obj'], slots['ctr'], slots['scl'],
+                slots['wgt'], slots['cls'], float(self._ignore_iou_thresh), slots['smooth'], losses.data_ptr(),
+                C.byref(dh), None, lws.data_ptr(), lws.numel())
+        fwd.append(seg)
+
+        # ---- backward
+        bwd, seg = [], Program()
+        written = set(self.head_names)     # gradients already produced (the loss kernel wrote d:head*)
+        dgrad_packs = []                   # (node, plan, packed weight buffer) re-packed when weights change
+
+        def grad_into(name, numel):
+            """Return (dst_ptr, accumulate?) for a producer of d:name."""
+            if name in written:
+                return bufs['d:' + name], True
+            written.add(name)
+            return bufs['d:' + name], False
+
+        for n in reversed(self.nodes):
+            if isinstance(n, UpcatNode):
+                dout = bufs['d:' + n.dst]
+                dup, acc_u = grad_into(n.up, 0)
+                drt, acc_r = grad_into(n.route, 0)
+                assert not acc_u
+                if acc_r:
+                    tmp = bufs['tmp'][:drt.numel()]
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), tmp.data_ptr(), B, dout.shape[1],
+                            dout.shape[2], n.cu, n.cr)
+                    seg.add('vd_add', drt.data_ptr(), tmp.data_ptr(), drt.data_ptr(), drt.numel())
+                else:
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), drt.data_ptr(), B, dout.shape[1],
+                            dout.shape[2], n.cu, n.cr)
+                continue
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            M = B * Ho * Wo
+            dy = bufs['d:' + n.dst]
+            assert n.dst in written, n.name
+            if n.head:
+                dz = dy
+                # bias gradient = per-channel sum of dz (reuses the BN column-sum kernels)
+                seg.add('vd_bn_stats', dz.data_ptr(), M, n.co_pad, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                seg.add('vd_bn_param_grads', n.sums.data_ptr(), n.co_pad, bufs['tmp'].data_ptr(), n.gbias.data_ptr())
+            else:
+                if n.residual:
+                    dres, acc = grad_into(n.residual, 0)
+                    if acc:
+                        seg.add('vd_add', dres.data_ptr(), dy.data_ptr(), dres.data_ptr(), dy.numel())
+                    else:
+                        # first producer of the skip gradient: it IS dy (copy = add with a zero-free form)
+                        seg.add('vd_bn_apply_leaky', dy.data_ptr(), self._ones(n.cout).data_ptr(),
+                                self._zeros(n.cout).data_ptr(), None, dres.data_ptr(), M, n.cout, 1.0)
+                z = bufs['z:' + n.dst]
+                dz = bufs['dz'][:M * n.cout].view(B, Ho, Wo, n.cout)
+                seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
+                        ws.data_ptr(), ws_bytes)
+                seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
+                count = float(M)
+                if self._syncbn(n):
+                    s2 = n.sums2
+                    seg = cut(bwd, seg, lambda s2=s2: torch.distributed.all_reduce(s2, group=self.process_group))
+                    count = float(M * world)
+                seg.add('vd_bn_bwd_apply', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
+                        dz.data_ptr())
+            # weight gradient straight into the gradient arena (same fwd-packed layout as the weights)
+            wd_ = WgradDesc()
+            xin = bufs['col'] if n.stem else bufs[n.src]
+            wd_.in_, wd_.dout, wd_.dwp = xin.data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
+            wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B, Hi, Wi, n.ci_eff
+            wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, n.co_pad
+            wd_.in_stride = n.stride
+            ops._set_taps(wd_, [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad))
+            wd_.Kfr, wd_.splits = 1, 0
+            seg.hold(wd_)
+            seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes)
+            if n.stem:
+                continue
+            # data gradient into d:src
+            dsrc, acc = grad_into(n.src, 0)
+            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi):
+                assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
+                wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
+                dgrad_packs.append((n, plan, wpk))
+                d = ConvDesc()
+                d.in_, d.wp, d.out = dz.data_ptr(), wpk.data_ptr(), dsrc.data_ptr()
+                d.N, d.Hi, d.Wi, d.Ci = B, Ho, Wo, n.co_pad
+                d.Hg, d.Wg, d.in_stride = plan['Hg'], plan['Wg'], 1
+                ops._set_taps(d, plan['taps'])
+                d.Kfr = 1
+                d.Ho, d.Wo, d.Co = Hi, Wi, n.cin
+                d.out_stride, d.out_oy, d.out_ox = n.stride, plan['py'], plan['px']
+                d.ldo = d.ldr = n.cin
+                d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
+                if acc:
+                    d.residual = dsrc.data_ptr()
+                seg.hold(d, wpk)
+                seg.add('vd_conv_igemm', C.byref(d))
+        bwd.append(seg)
+        return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=dgrad_packs, ws=ws)
+
+    def _ones(self, c):
+        if not hasattr(self, '_const'):
+            self._const = (torch.ones(1024, device=self.device), torch.zeros(1024, device=self.device))
+        return self._const[0]
+
+    def _zeros(self, c):
+        self._ones(c)
+        return self._const[1]
+
+    def _refresh_dgrad(self, tp):
+        if not self._dgrad_dirty:
+            return
+        for n, plan, wpk in tp['dgrad_packs']:
+            ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=1, kh=n.k, kw=n.k,
+                                  tap_ids=plan['tap_ids'], src_packed=True)
+        self._dgrad_dirty = False
+
+    @staticmethod
+    def _run_segments(segs):
+        for s in segs:
+            if isinstance(s, Program):
+                s.run()
+            else:
+                s()
+
+    def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
+        B, _, H, W = x.shape
+        key = ('train', B, H, W)
+        if key not in self._programs:
+            self._programs[key] = self._build_train(B, H, W)
+        tp = self._programs[key]
+        f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        gt, obj, ctr, scl, wgt, cls = [f32(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
+        tp['live'] = (gt, obj, ctr, scl, wgt, cls)
+        s = tp['slots']
+        s['gt'].value, s['M'].value = gt.data_ptr(), int(gt.shape[1])
+        s['obj'].value, s['ctr'].value, s['scl'].value = obj.data_ptr(), ctr.data_ptr(), scl.data_ptr()
+        s['wgt'].value, s['cls'].value = wgt.data_ptr(), cls.data_ptr()
+        s['smooth'].value = 1 if self._label_smooth else 0
+        tp['bufs']['in'].copy_(x)
+        self._run_segments(tp['fwd'])
+        self._fold_dirty = True            # running stats moved
+        self._last_train = tp
+        L_ = tp['losses']
+        return L_[:, 0], L_[:, 1], L_[:, 2], L_[:, 3]
+
+    def backward(self):
+        """autograd.backward(sum_losses) (train_yolov3.py:631): gradient of the sum of all four losses over the
+        local batch wrt every parameter, written into the gradient arena."""
+        tp = self._last_train
+        self._refresh_dgrad(tp)
+        self._run_segments(tp['bwd'])
+
+    # ------------------------------------------------------------------ call protocol
+    def __call__(self, x, *args):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected a (B,3,H,W) batch, got %s" % (tuple(x.shape),))
+        if len(args) == 0:
+            return self._forward_infer(x)
+        if len(args) != 6:
+            raise TypeError("training call takes (x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)")
+        return self._forward_train(x, *args)
+
+    # ------------------------------------------------------------------ optimiser / DP hooks
+    def allreduce_grads(self):
+        """kvstore-'local' replacement (train_yolov3.py:530): one RCCL sum all-reduce of the flat gradient arena."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.process_group) > 1:
+            torch.distributed.all_reduce(self.grads, group=self.process_group)
+
+    def sgd_step(self, lr, momentum, wd, batch_size, no_wd=False):
+        """gluon.Trainer('sgd').step(batch_size) (train_yolov3.py:527-530,634); wd_mult=0 on gamma/beta/bias
+        with --no_wd (:495-497)."""
+        rescale = 1.0 / float(batch_size)
+        nw = self.n_weight
+        ops.sgd_momentum(self.weights[:nw], self.grads[:nw], self.momentum_buf[:nw], lr, momentum, wd, rescale)
+        ops.sgd_momentum(self.weights[nw:], self.grads[nw:], self.momentum_buf[nw:], lr, momentum,
+                         0.0 if no_wd else wd, rescale)
+        self._params_changed()
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_arrays(self):
+        return OrderedDict((k, p.data().cpu().numpy()) for k, p in self._params.items())
+
+    def save_parameters(self, path):
+        from .params_io import save_params
+        save_params(path, self.state_arrays())
+
+    def load_parameters(self, path, allow_missing=False, ignore_extra=False):
+        from .params_io import load_params
+        arrs = load_params(path)
+        for k, p in self._params.items():
+            if k in arrs:
+                p.set_data(torch.from_numpy(np.ascontiguousarray(arrs[k], dtype=np.float32)))
+            elif not allow_missing and not re.search(r"(anchor|offset)", k):
+                raise KeyError("parameter %s missing in %s" % (k, path))
+        if not ignore_extra:
+            extra = [k for k in arrs if k not in self._params and not re.search(r"(anchor|offset)", k)]
+            if extra:
+                raise KeyError("unexpected parameters in %s: %s" % (path, extra[:5]))
+
+
+def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs=None, freeze_base=False,
+                    k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', **kwargs):
+    """wrappers.py:9-110.  norm_layer='syncbn' (the reference passes SyncBatchNorm) selects the SyncBN collective."""
+    if k not in (None, 1):
+        raise NotImplementedError("temporal windows (k>1) are built by viddet_amd.temporal (not wired yet)")
+    if block_conv_type != '2':
+        raise AssertionError("k must be greater than 1 to use 3D or 2+1D convolutions")   # yolo3.py:979
+    scope = None
+    if norm_layer == 'syncbn':
+        scope = (norm_kwargs or {}).get('scope', 'all')
+    net = YOLOV3(classes, syncbn_scope=scope, **kwargs)
+    if freeze_base:
+        for name, p in net.collect_params('stages.*').items():
+            p.grad_req = 'null'
+    return net
