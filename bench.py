@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the yolo3_darknet53 hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--mode train|detect] [--batch B] [--size S] [--classes C]
+
+mode train  (default; BASELINE.json configs[2]): yolo3_darknet53_coco, per-GPU batch 64, 416x416, fp32,
+            one step = forward + 4 losses + backward + gradient all-reduce (N>1) + SGD-momentum update.
+mode detect (BASELINE.json configs[1] shape): forward + decode + NMS at 608x608.
+Inputs are synthetic, resident in HBM before the timed region; weights random-init (He).
+For N>1 the driver launches one rank per GPU with torch.distributed.run; ranks shard frames (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="train", choices=["train", "detect"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 train / 32 detect)")
+    ap.add_argument("--size", type=int, default=0, help="input side (default 416 train / 608 detect)")
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, size, classes):
+    """The NumPy oracle (a port, not MXNet) timed on this box's host cores on ONE frame of the same workload."""
+    from oracle import net as ON
+    from oracle import yolo as Y
+    from viddet_amd.targets import synthetic_batch
+    P = ON.init_params(classes, seed=233, obj_bias=-4.0)
+    x, gt, ids = synthetic_batch(1, size, classes, 233)
+    onet = ON.Net(P, classes)
+    x64 = x.astype(np.float64)
+    t0 = time.time()
+    if mode == "train":
+        tg = Y.prefetch_targets(size, size, [size // 32, size // 16, size // 8], gt.astype(np.float64), ids, classes)
+        onet.train_step(x64, gt.astype(np.float64), *tg)
+        sample = "1 frame %dx%d, fwd+loss+bwd, NumPy fp64 oracle (OpenBLAS threads)" % (size, size)
+    else:
+        onet.detect(x64)
+        sample = "1 frame %dx%d, fwd+decode+NMS, NumPy fp64 oracle (OpenBLAS threads)" % (size, size)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from viddet_amd.model import yolo3_darknet53
+    from viddet_amd.targets import synthetic_batch, prefetch_targets
+
+    train = a.mode == "train"
+    B = a.batch or (64 if train else 32)
+    S = a.size or (416 if train else 608)
+    C = a.classes
+    classes = ["c%d" % i for i in range(C)]
+    net = yolo3_darknet53(classes, norm_layer="syncbn" if a.syncbn else None,
+                          norm_kwargs={"scope": a.syncbn} if a.syncbn else None)
+    # He init keeps synthetic activations O(1); objectness bias negative so only a few % of the C*P score rows
+    # pass valid_thresh, as with a trained net.  Same seed on every rank => identical replicas.
+    net.initialize(init="he", seed=233, obj_bias=-4.0)
+    x_np, gt_np, ids_np = synthetic_batch(B, S, C, 233 + rank)
+    x = torch.from_numpy(x_np).cuda()
+    if train:
+        tg = prefetch_targets(S, S, gt_np, ids_np, C)
+        gt = torch.from_numpy(gt_np).cuda()
+        tgd = [torch.from_numpy(t).cuda() for t in tg]
+        lr, mom, wd = 1e-3, 0.9, 5e-4      # train_yolov3.py:78,91-94 defaults
+
+        def step():
+            net(x, gt, *tgd)
+            net.backward()
+            net.allreduce_grads()
+            net.sgd_step(lr, mom, wd, batch_size=B * world)
+    else:
+        def step():
+            net(x)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * B * a.steps / dt
+
+    # ---- roofline of the dominant kernel (k_conv_igemm: forward + data-gradient convs), measured live with
+    # events on the launch stream over one more step
+    roof = None
+    extra = {}
+    if rank == 0:
+        recs = []
+        if train:
+            net(x, gt, *tgd)
+            tp = net._last_train
+            net._refresh_dgrad(tp)
+            for seg in tp["fwd"] + tp["bwd"]:
+                if hasattr(seg, "run_timed"):
+                    recs += seg.run_timed({"vd_conv_igemm", "vd_conv_wgrad"})
+                else:
+                    seg()
+        else:
+            prog = net._programs[("infer", B, S, S)][0]
+            recs = prog.run_timed({"vd_conv_igemm"})
+        torch.cuda.synchronize()
+        agg = {}
+        for fname, meta, e0, e1 in recs:
+            ms = e0.elapsed_time(e1)
+            key = fname
+            v = agg.setdefault(key, [0.0, 0.0, 0])
+            v[0] += meta["flops"]
+            v[1] += ms
+            v[2] += 1
+            if fname == "vd_conv_igemm" and meta["k"] == 3 and meta["stride"] == 1 and meta["kind"] == "fwd":
+                w = agg.setdefault("igemm_3x3s1_fwd", [0.0, 0.0, 0])
+                w[0] += meta["flops"]; w[1] += ms; w[2] += 1
+        ig = agg["vd_conv_igemm"]
+        ach = ig[0] / (ig[1] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "k_conv_igemm (fp32 v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches": ig[2], "avg_launch_ms": round(ig[1] / ig[2], 4),
+                "algorithmic_gflop_per_launch": round(ig[0] / ig[2] / 1e9, 3)}
+        for k, v in agg.items():
+            if k != "vd_conv_igemm" and v[1] > 0:
+                extra[k] = {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
+        extra["conv_ms_per_step"] = round(sum(v[1] for k, v in agg.items() if k.startswith("vd_")), 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.mode, S, C)
+
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        gflop = 197.3 if (train and S == 416 and C == 80) else None
+        out = {
+            "metric": ("frames/sec (%dx%d) yolo3_darknet53 fwd+bwd" % (S, S)) if train else
+                      ("detect fps (%dx%d) yolo3_darknet53 fwd+decode+NMS" % (S, S)),
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
+                                    "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
+                       else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, fp32" % (B, S, S)),
+                       "classes": C, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "syncbn": a.syncbn},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": extra,
+        }
+        if gflop:
+            out["model_tflops"] = round(fps * gflop / 1e3, 2)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""Sample contract of the reference's datasets + the two transforms its scripts use, for synthetic frames.
+
+Mirrors (paths under /root/reference):
+  Dataset.__getitem__ -> (img HWC uint8, label (N,6) [x1,y1,x2,y2,cls,difficult])   datasets/pascalvoc.py:94-127
+  YOLO3VideoTrainTransform.__call__       models/definitions/yolo/transforms.py:199-294  (fixed-shape path)
+  YOLO3VideoInferenceTransform.__call__   models/definitions/yolo/transforms.py:316-350
+  batchify: Stack images/targets, Pad(-1) gt boxes                                   train_yolov3.py:252-256
+The real file-system readers (VOC/COCO/DET/VID) are out of scope: no dataset files
+exist offline and the headline metric is quoted on synthetic frames.  Class counts are kept.
+"""
+import numpy as np
+
+from . import bbox as tbbox
+from .targets import prefetch_targets
+
+NUM_CLASSES = {"voc": 20, "coco": 80, "det": 200, "vid": 30, "comb": 285, "synthetic": 20}
+MEAN = np.array([0.485, 0.456, 0.406], np.float32)     # transforms.py:167
+STD = np.array([0.229, 0.224, 0.225], np.float32)      # transforms.py:168
+
+
+class SyntheticDetection:
+    """Deterministic synthetic dataset: uint8 frames with `max_gt` random boxes."""
+
+    def __init__(self, name="synthetic", num_samples=64, size=(480, 360), num_class=None, max_gt=8, seed=233):
+        self.name = name
+        self.num_class = NUM_CLASSES.get(name, 20) if num_class is None else num_class
+        self.classes = ["class%d" % i for i in range(self.num_class)]
+        self._n, self._size, self._max_gt, self._seed = num_samples, size, max_gt, seed
+
+    def __len__(self):
+        return self._n
+
+    def sample_path(self, idx):
+        return "synthetic/%06d.jpg" % idx
+
+    def __getitem__(self, idx):
+        rng = np.random.default_rng(self._seed * 1000003 + idx)
+        w, h = self._size
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        n = int(rng.integers(1, self._max_gt + 1))
+        c = rng.uniform(0.1, 0.9, (n, 2)) * (w, h)
+        wh = rng.uniform(16, 0.5 * min(w, h), (n, 2))
+        box = np.concatenate([np.clip(c - wh / 2, 0, (w - 1, h - 1)), np.clip(c + wh / 2, 0, (w - 1, h - 1))], axis=1)
+        cls = rng.integers(0, self.num_class, (n, 1)).astype(np.float64)
+        return img, np.concatenate([box, cls, np.zeros((n, 1))], axis=1)
+
+
+def _resize_nearest(img, w, h):
+    """Host resize to (h,w).  The reference uses mx.image.imresize (interp 9 / random 0-4, transforms.py:229,332),
+    an OpenCV call that is not reproducible offline; nearest sampling keeps the pipeline self-contained."""
+    ih, iw = img.shape[:2]
+    ys = np.minimum((np.arange(h) * (ih / h)).astype(np.int64), ih - 1)
+    xs = np.minimum((np.arange(w) * (iw / w)).astype(np.int64), iw - 1)
+    return img[ys][:, xs]
+
+
+def _to_tensor_normalize(img):
+    x = img.astype(np.float32) / 255.0            # mx.nd.image.to_tensor
+    x = (x - MEAN) / STD                          # mx.nd.image.normalize
+    return np.ascontiguousarray(x.transpose(2, 0, 1))
+
+
+class YOLO3VideoInferenceTransform:
+    """transforms.py:297-350: resize to (width,height), to_tensor, normalize; boxes resized along."""
+
+    def __init__(self, width, height):
+        self._w, self._h = width, height
+
+    def __call__(self, img, label, idx=0):
+        h, w = img.shape[:2]
+        out = _to_tensor_normalize(_resize_nearest(img, self._w, self._h))
+        bb = tbbox.resize(label, (w, h), (self._w, self._h))
+        return out, bb.astype(np.float32), idx
+
+
+class YOLO3VideoTrainTransform:
+    """transforms.py:143-294, fixed-shape path: random horizontal flip, resize, normalise, prefetch targets."""
+
+    def __init__(self, width, height, num_class, rng=None):
+        self._w, self._h, self._c = width, height, num_class
+        self._rng = np.random.default_rng(0) if rng is None else rng
+
+    def __call__(self, img, label):
+        h, w = img.shape[:2]
+        bb = tbbox.resize(label, (w, h), (self._w, self._h))
+        im = _resize_nearest(img, self._w, self._h)
+        if self._rng.random() < 0.5:                                  # transforms.py:233-236
+            im = im[:, ::-1]
+            bb = tbbox.flip(bb, (self._w, self._h), flip_x=True)
+        x = _to_tensor_normalize(im)
+        gt = bb[np.newaxis, :, :4]
+        ids = bb[np.newaxis, :, 4:5]
+        obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c)
+        return x, obj[0], ctr[0], scl[0], wgt[0], cls[0], gt[0].astype(np.float32)
+
+
+def pad_stack(arrs, pad_val=-1.0):
+    m = max(a.shape[0] for a in arrs)
+    out = np.full((len(arrs), m) + arrs[0].shape[1:], pad_val, dtype=np.float32)
+    for i, a in enumerate(arrs):
+        out[i, :a.shape[0]] = a
+    return out
+
+
+class Loader:
+    """Minimal single-process loader (the reference's multi-worker DataLoader only feeds the host pipeline)."""
+
+    def __init__(self, dataset, transform, batch_size, train, shuffle=False, last_batch="rollover", seed=0,
+                 rank=0, world=1):
+        self.ds, self.tf, self.bs, self.train = dataset, transform, batch_size, train
+        self.shuffle, self.last_batch, self._rng = shuffle, last_batch, np.random.default_rng(seed)
+        self.rank, self.world = rank, world
+
+    def __len__(self):
+        n = len(self.ds) // self.world
+        return n // self.bs if self.last_batch != "keep" else (n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        idx = np.arange(len(self.ds))
+        if self.shuffle:
+            self._rng.shuffle(idx)
+        idx = idx[self.rank::self.world]                 # frames are sharded across ranks, windows never split
+        for i in range(len(self)):
+            chunk = idx[i * self.bs:(i + 1) * self.bs]
+            if self.train:
+                cols = list(zip(*[self.tf(*self.ds[int(j)]) for j in chunk]))
+                yield [np.stack(c) for c in cols[:6]] + [pad_stack(cols[6])]
+            else:
+                cols = list(zip(*[self.tf(*self.ds[int(j)], int(j)) for j in chunk]))
+                yield np.stack(cols[0]), pad_stack(cols[1]), np.asarray(cols[2])

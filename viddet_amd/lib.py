@@ -102,6 +102,11 @@ def load():
         raise VidDetHipError(
             "libviddet_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C viddet_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime (libamdhip64.so): it must be resident BEFORE this library is
+    # dlopen'ed so that both resolve to ONE runtime (the device memory torch allocates and the stream it
+    # hands over must belong to the runtime that launches these kernels).  Loading /opt/rocm's copy first
+    # yields a second runtime that reports "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,0 +1,105 @@
+"""Host-side evaluation metrics with the reference's interface.
+
+Mirrors metrics/pascalvoc.py:14-259 (VOCMApMetric: update / get / reset; area-under-PR AP, IoU >= 0.5
+match to the arg-max ground truth, no +1 pixel offset — the `+= 1` is commented out at :162-164) and
+mx.metric.Loss as used at train_yolov3.py:537-540,637-640 (running mean of per-sample losses).
+"""
+import numpy as np
+
+from .bbox import bbox_iou
+
+
+class LossMetric:
+    """mx.metric.Loss: update(_, [losses]) accumulates sum and count; get() -> (name, mean)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.reset()
+
+    def reset(self):
+        self.sum_metric, self.num_inst = 0.0, 0
+
+    def update(self, _, preds):
+        for p in preds if isinstance(preds, (list, tuple)) else [preds]:
+            a = p.detach().cpu().numpy() if hasattr(p, "detach") else np.asarray(p)
+            self.sum_metric += float(a.sum())
+            self.num_inst += int(a.size)
+
+    def get(self):
+        return self.name, (self.sum_metric / self.num_inst if self.num_inst else float("nan"))
+
+
+class VOCMApMetric:
+    def __init__(self, iou_thresh=0.5, class_names=None):
+        if class_names is None:
+            raise ValueError("class_names is required")
+        self.class_names = list(class_names)
+        self.num = len(self.class_names)
+        self.iou_thresh = iou_thresh
+        self.reset()
+
+    def reset(self):
+        self._npos = np.zeros(self.num, dtype=np.int64)
+        self._scores = [[] for _ in range(self.num)]
+        self._hits = [[] for _ in range(self.num)]      # 1 = true positive, 0 = false positive, -1 = ignored
+
+    def update(self, pred_bboxes, pred_labels, pred_scores, gt_bboxes, gt_labels, gt_difficults=None):
+        """Arguments are lists (or batched arrays) over images, as validate() passes them (train_yolov3.py:487)."""
+        n = len(pred_bboxes)
+        if gt_difficults is None:
+            gt_difficults = [None] * n
+        for i in range(n):
+            pb, pl, ps = np.asarray(pred_bboxes[i]), np.asarray(pred_labels[i]).reshape(-1), np.asarray(pred_scores[i]).reshape(-1)
+            gb, gl = np.asarray(gt_bboxes[i]), np.asarray(gt_labels[i]).reshape(-1)
+            keep_p, keep_g = pl >= 0, gl >= 0
+            pb, pl, ps = pb.reshape(-1, 4)[keep_p], pl[keep_p].astype(int), ps[keep_p]
+            gb, gl = gb.reshape(-1, 4)[keep_g], gl[keep_g].astype(int)
+            gd = np.zeros(len(gl)) if gt_difficults[i] is None else np.asarray(gt_difficults[i]).reshape(-1)[keep_g]
+            for c in np.union1d(pl, gl):
+                sel_p, sel_g = pl == c, gl == c
+                order = np.argsort(-ps[sel_p], kind="stable")     # pascalvoc.py:137 sorts score-descending
+                boxes, scores = pb[sel_p][order], ps[sel_p][order]
+                gboxes, gdiff = gb[sel_g], gd[sel_g].astype(bool)
+                self._npos[c] += int((~gdiff).sum())
+                self._scores[c].extend(scores.tolist())
+                if len(boxes) == 0:
+                    continue
+                if len(gboxes) == 0:
+                    self._hits[c].extend([0] * len(boxes))
+                    continue
+                iou = bbox_iou(boxes, gboxes)
+                best = iou.argmax(axis=1)
+                best[iou.max(axis=1) < self.iou_thresh] = -1
+                taken = np.zeros(len(gboxes), dtype=bool)
+                for g in best:
+                    if g < 0:
+                        self._hits[c].append(0)
+                    elif gdiff[g]:
+                        self._hits[c].append(-1)
+                        taken[g] = True
+                    else:
+                        self._hits[c].append(0 if taken[g] else 1)
+                        taken[g] = True
+
+    def _ap(self, c):
+        if self._npos[c] == 0 and not self._scores[c]:
+            return np.nan
+        s = np.asarray(self._scores[c])
+        h = np.asarray(self._hits[c], dtype=np.int64)[np.argsort(-s, kind="stable")] if len(s) else np.zeros(0, np.int64)
+        tp, fp = np.cumsum(h == 1), np.cumsum(h == 0)
+        if self._npos[c] == 0:
+            return np.nan
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prec = np.nan_to_num(tp / (tp + fp))
+        rec = tp / self._npos[c]
+        # area under the monotone precision envelope (pascalvoc.py:229-259)
+        mrec = np.concatenate([[0.0], rec, [1.0]])
+        mpre = np.concatenate([[0.0], prec, [0.0]])
+        mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+        idx = np.nonzero(mrec[1:] != mrec[:-1])[0]
+        return float(((mrec[idx + 1] - mrec[idx]) * mpre[idx + 1]).sum())
+
+    def get(self):
+        """-> (names + ['mAP'], values) as the reference returns (pascalvoc.py:51-66)."""
+        aps = [self._ap(c) for c in range(self.num)]
+        return self.class_names + ["mAP"], aps + [float(np.nanmean(aps)) if np.any(~np.isnan(aps)) else float("nan")]

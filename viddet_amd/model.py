@@ -46,11 +46,13 @@ class Program:
 
     def __init__(self):
         self.recs = []
+        self.meta = []          # per-record info (kind, algorithmic flops) for the roofline accounting
         self.keep = []          # descriptor structs / tensors the records point into
 
-    def add(self, fname, *args):
+    def add(self, fname, *args, meta=None):
         fn = getattr(L.load(), fname)
         self.recs.append((fname, fn, args))
+        self.meta.append(meta)
 
     def hold(self, *objs):
         self.keep.extend(objs)
@@ -62,6 +64,25 @@ class Program:
             rc = fn(*a, s)
             if rc != 0:
                 L.check(rc, fname)
+
+    def run_timed(self, select):
+        """Replay with a (start, stop) event pair around every record whose entry point is in `select`;
+        events sit on the stream the kernels are launched on.  Returns [(fname, meta, start, stop)]."""
+        s = L.stream_ptr()
+        out = []
+        for (fname, fn, args), meta in zip(self.recs, self.meta):
+            a = [x.value if isinstance(x, Slot) else x for x in args]
+            if fname in select:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*a, s)
+                e1.record()
+                out.append((fname, meta, e0, e1))
+            else:
+                rc = fn(*a, s)
+            if rc != 0:
+                L.check(rc, fname)
+        return out
 
 
 class Parameter:
@@ -481,7 +502,7 @@ class YOLOV3(object):
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
                                     leaky=True)
             prog.hold(d)
-            prog.add('vd_conv_igemm', C.byref(d))
+            prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
         grids = self._grid(H, W)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
                                 STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
@@ -585,12 +606,12 @@ class YOLOV3(object):
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
                 seg.hold(d)
-                seg.add('vd_conv_igemm', C.byref(d))
+                seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
                 continue
             z = bufs['z:' + n.dst]
             d = self._conv_desc(n, bufs, B, H, W, z)
             seg.hold(d)
-            seg.add('vd_conv_igemm', C.byref(d))
+            seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
             seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
             count = float(M)
             if self._syncbn(n):
@@ -687,7 +708,7 @@ class YOLOV3(object):
             ops._set_taps(wd_, [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad))
             wd_.Kfr, wd_.splits = 1, 0
             seg.hold(wd_)
-            seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes)
+            seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
             if n.stem:
                 continue
             # data gradient into d:src
@@ -709,9 +730,17 @@ class YOLOV3(object):
                 if acc:
                     d.residual = dsrc.data_ptr()
                 seg.hold(d, wpk)
-                seg.add('vd_conv_igemm', C.byref(d))
+                seg.add('vd_conv_igemm', C.byref(d), meta=dict(
+                    kind='dgrad', node=n.name, k=n.k, stride=n.stride,
+                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B))
         bwd.append(seg)
         return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=dgrad_packs, ws=ws)
+
+    @staticmethod
+    def _flops(n, B, H, W, kind):
+        """Algorithmic FLOPs of one conv launch: 2*Cin*Cout*k*k*Ho*Wo per image."""
+        return dict(kind=kind, node=n.name, k=n.k, stride=n.stride,
+                    flops=2.0 * n.cin * n.cout * n.k * n.k * (H // n.div_out) * (W // n.div_out) * B)
 
     def _ones(self, c):
         if not hasattr(self, '_const'):
