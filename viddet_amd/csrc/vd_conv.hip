@@ -25,38 +25,23 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-struct RowInfo {
-    int pix;   // pixel index n*Hi*Wi + iy0*Wi + ix0 of tap (0,0,0); -1 if the row is out of range
-    int pk;    // iy0 | ix0<<12 | fz<<24
-};
+// a resident page of zeros: the load target of padded / out-of-window rows (see load_a_chunk)
+__device__ __attribute__((aligned(64))) float g_zero_page[64];
 
-template <bool XF>
-__device__ __forceinline__ f32x4 load_a_chunk(const vd_conv_desc& p, const RowInfo ri, int dy, int dx,
-                                              int dz, int doff, int coff, const f32x4 sc,
-                                              const f32x4 sh) {
-    const int iy = (ri.pk & 0xfff) + dy;
-    const int ix = ((ri.pk >> 12) & 0xfff) + dx;
-    const int fz = ((ri.pk >> 24) & 0x7f) + dz;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ri.pix >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
-        (unsigned)fz < (unsigned)p.Kfr) {
-        v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)(ri.pix + doff) * p.Ci + coff));
-        if (XF) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[e] * sc[e] + sh[e];
-                v[e] = t > 0.f ? t : t * p.in_slope;
-            }
-        }
-    }
-    return v;
-}
+struct RowInfo {
+    int64_t off;     // element offset of (pixel of tap (0,0,0), channel lc4) in `in`
+    unsigned mask;   // bit t set <=> tap t of this row lies inside the image / temporal window
+};
 
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel
+//   zd_in / zd_w: element offsets (relative to p.in / p.wp) of a resident page of zeros.  Rows that
+//   fall outside the image, the temporal window, M or Co read that page, so every load of a K-step
+//   is unconditional (one v_cndmask on the offset, no exec-masked branch per load) and the loop
+//   body is one straight-line stream.
 // ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, bool XF>
-__global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
+__global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     static_assert(WM * WN == 4, "4 waves");
@@ -79,24 +64,33 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int64_t m = (int64_t)tile_m * BM + lrow + 32 * i;
+        ri[i].off = 0;
+        ri[i].mask = 0u;
         if (m < M) {
-            const int gx = (int)(m % p.Wg);
-            const int64_t t = m / p.Wg;
-            const int gy = (int)(t % p.Hg);
-            const int n = (int)(t / p.Hg);
+            // M < 2^31 (checked on the host): 32-bit divisions instead of the 64-bit slow path
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)p.Wg;
+            const int gx = (int)(mu - t * (unsigned)p.Wg);
+            const unsigned n_ = t / (unsigned)p.Hg;
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            const int n = (int)n_;
             const int iy0 = gy * p.in_stride, ix0 = gx * p.in_stride;
-            ri[i].pix = (n * p.Hi + iy0) * p.Wi + ix0;
-            ri[i].pk = iy0 | (ix0 << 12) | ((n % p.Kfr) << 24);
-        } else {
-            ri[i].pix = -1;
-            ri[i].pk = 0;
+            const int fz0 = n % p.Kfr;
+            ri[i].off = (int64_t)((n * p.Hi + iy0) * p.Wi + ix0) * p.Ci + lc4;
+            unsigned mk = 0u;
+            for (int t2 = 0; t2 < p.T; ++t2) {
+                const bool ok = (unsigned)(iy0 + p.dy[t2]) < (unsigned)p.Hi && (unsigned)(ix0 + p.dx[t2]) < (unsigned)p.Wi &&
+                                (unsigned)(fz0 + p.dz[t2]) < (unsigned)p.Kfr;
+                mk |= ok ? (1u << t2) : 0u;
+            }
+            ri[i].mask = mk;
         }
     }
-    const float* bptr[BP];
+    int64_t boff[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
         const int n = tile_n * BN + lrow + 32 * i;
-        bptr[i] = (n < p.Co) ? p.wp + (int64_t)n * Ktot + lc4 : nullptr;
+        boff[i] = (n < p.Co) ? (int64_t)n * Ktot + lc4 : (int64_t)-1;       // -1: row beyond Co reads zeros
     }
 
     f32x16 acc[TM][TN];
@@ -112,21 +106,34 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
 
     auto gload = [&]() {
         const int dy = p.dy[t_tap], dx = p.dx[t_tap], dz = p.dz[t_tap];
-        const int doff = (dz * p.Hi + dy) * p.Wi + dx;
-        const int coff = c0 + lc4;
+        const int64_t soff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + c0;     // wave-uniform
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (XF) {
-            sc = *reinterpret_cast<const f32x4*>(p.in_scale + coff);
-            sh = *reinterpret_cast<const f32x4*>(p.in_shift + coff);
+            sc = *reinterpret_cast<const f32x4*>(p.in_scale + c0 + lc4);
+            sh = *reinterpret_cast<const f32x4*>(p.in_shift + c0 + lc4);
         }
 #pragma unroll
-        for (int i = 0; i < AP; ++i) ra[i] = load_a_chunk<XF>(p, ri[i], dy, dx, dz, doff, coff, sc, sh);
-        const int koff = t_tap * p.Ci + c0;
+        for (int i = 0; i < AP; ++i) {
+            const bool ok = (ri[i].mask >> t_tap) & 1u;
+            const int64_t o = ri[i].off + soff;
+            const int64_t sel = ok ? o : zd_in;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.in + sel);
+            if (XF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e] * sc[e] + sh[e];
+                    t = t > 0.f ? t : t * p.in_slope;
+                    v[e] = ok ? t : 0.f;
+                }
+            }
+            ra[i] = v;
+        }
+        const int64_t koff = (int64_t)t_tap * p.Ci + c0;
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (bptr[i]) v = *reinterpret_cast<const f32x4*>(bptr[i] + koff);
-            rb[i] = v;
+            const int64_t o = boff[i] + koff;
+            const int64_t sel = boff[i] >= 0 ? o : zd_w;
+            rb[i] = *reinterpret_cast<const f32x4*>(p.wp + sel);
         }
         c0 += BK;
         if (c0 >= p.Ci) { c0 = 0; ++t_tap; }
@@ -198,10 +205,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
                 if (!cok || m >= M) continue;
                 int64_t opix = m;
                 if (!direct) {
-                    const int gx = (int)(m % p.Wg);
-                    const int64_t t = m / p.Wg;
-                    const int gy = (int)(t % p.Hg);
-                    const int64_t n = t / p.Hg;
+                    const unsigned mu = (unsigned)m;
+                    const unsigned t = mu / (unsigned)p.Wg;
+                    const int gx = (int)(mu - t * (unsigned)p.Wg);
+                    const int64_t n = t / (unsigned)p.Hg;
+                    const int gy = (int)(t - (unsigned)n * (unsigned)p.Hg);
                     opix = (n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
                 }
                 float v = acc[mi][ni][r];
@@ -212,6 +220,16 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p) {
             }
         }
     }
+}
+
+const float* zero_page() {
+    static const float* zp = nullptr;
+    if (!zp) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) != hipSuccess) q = nullptr;
+        zp = (const float*)q;
+    }
+    return zp;
 }
 
 template <int WM, int WN, int TM, int TN, bool XF>
@@ -226,7 +244,9 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
     }
     const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
     const int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(256), lds, s, d);
+    const float* zp = zero_page();
+    const int64_t zd_in = zp - d.in, zd_w = zp - d.wp;      // element deltas (all pointers are float-aligned)
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(256), lds, s, d, zd_in, zd_w);
     return 0;
 }
 
@@ -242,114 +262,131 @@ int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradient:  D[co][t*Ci+c] = sum_pix dout[pix][co] * in[pix shifted by tap t][c]
-//   GEMM rows = co, cols = c (inside one tap), reduction = pixels.  Both operands are
-//   channel-contiguous per pixel, so the LDS tiles are [pixel][128] and the MFMA operands are
-//   fetched with conflict-free ds_read_b32 (lane -> channel, half-wave -> pixel parity).
+// weight gradient:  D[co][j] = sum_pix dout[pix][co] * in[pix shifted by tap(j)][c(j)],  j = t*Ci + c
+//   GEMM rows = co, cols = the flat (tap, channel) index j (exactly the packed weight layout), reduction
+//   = pixels.  Both operands are channel-contiguous per pixel, so the LDS tiles are [pixel][BM|128] and
+//   the MFMA operands are fetched with conflict-free ds_read_b32 (lane -> channel, half-wave -> pixel
+//   parity).  A thread's 4-column chunk never straddles a tap (Ci % 4 == 0), so each thread owns one
+//   (tap, channel) for the whole reduction: narrow layers (Ci = 32/64) fill the 128-wide tile with 4 / 2
+//   taps instead of wasting it, and the dout tile is shared by those taps.
+//   Tiles <WM,WN,TM,TN>: 128x128 (2,2,2,2), 64x128 (2,2,1,2), 32x128 (1,4,1,1) by Co.
 // ---------------------------------------------------------------------------------------------
-constexpr int WG_BM = 128, WG_BN = 128, WG_BP = 32;
+constexpr int WG_BN = 128, WG_BP = 32;
 
-template <bool XF>
+template <int WM, int WN, int TM, int TN, bool XF>
 __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
-                                                    int splits, int64_t pix_per_split) {
+                                                    int splits, int64_t pix_per_split, const int64_t zd_in,
+                                                    const int64_t zd_do) {
+    constexpr int BM = WM * TM * 32;
+    static_assert(WN * TN * 32 == WG_BN && WM * WN == 4, "tile");
+    constexpr int AROWS = 1024 / BM;          // pixel rows of the dout tile one pass of 256 float4 lanes covers
+    constexpr int APASS = WG_BP / AROWS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [2][WG_BP][WG_BM]   dout
-    float* Bs = smem + 2 * WG_BP * WG_BM;     // [2][WG_BP][WG_BN]   in
+    float* As = smem;                         // [2][WG_BP][BM]      dout
+    float* Bs = smem + 2 * WG_BP * BM;        // [2][WG_BP][WG_BN]   in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ctiles = (p.Ci + WG_BN - 1) / WG_BN;
-    const int mtiles = (p.Co + WG_BM - 1) / WG_BM;
-    // block -> (split, tap, ctile, mtile)
+    const int wm = wave / WN, wn = wave % WN;
+    const int Ktot = p.T * p.Ci;
+    const int jtiles = (Ktot + WG_BN - 1) / WG_BN;
+    const int mtiles = (p.Co + BM - 1) / BM;
+    // block -> (split, jtile, mtile)
     int b = blockIdx.x;
     const int tile_m = b % mtiles; b /= mtiles;
-    const int tile_c = b % ctiles; b /= ctiles;
-    const int tap = b % p.T;
-    const int split = b / p.T;
+    const int tile_j = b % jtiles;
+    const int split = b / jtiles;
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
     const int64_t p_begin = (int64_t)split * pix_per_split;
     int64_t p_end = p_begin + pix_per_split;
     if (p_end > P) p_end = P;
-    const int Ktot = p.T * p.Ci;
 
+    // B operand: this thread's column chunk -> (tap, channel), fixed for the whole reduction
+    const int blpix = tid >> 5;               // 0..7 : pixel row inside a pass
+    const int blc = (tid & 31) * 4;
+    const int j = tile_j * WG_BN + blc;
+    const bool j_ok = j < Ktot;
+    const int tap = j_ok ? j / p.Ci : 0;
+    const int ci = j_ok ? j - tap * p.Ci : 0;
     const int dy = p.dy[tap], dx = p.dx[tap], dz = p.dz[tap];
-    const int doff = (dz * p.Hi + dy) * p.Wi + dx;
-
-    const int lpix = tid >> 5;          // 0..7 : pixel row inside a pass
-    const int lc = (tid & 31) * 4;      // channel offset inside the 128-wide tile
-    const int co = tile_m * WG_BM + lc;
-    const int ci = tile_c * WG_BN + lc;
-    const bool co_ok = co < p.Co;       // Co, Ci multiples of 4 => whole float4 in or out
-    const bool ci_ok = ci < p.Ci;
+    const int64_t boff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + ci;
+    // A operand (dout)
+    const int alpix = tid / (BM / 4);
+    const int alc = (tid % (BM / 4)) * 4;
+    const int co = tile_m * BM + alc;
+    const bool co_ok = co < p.Co;             // Co, Ci multiples of 4 => whole float4 in or out
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (XF && ci_ok) {
+    if (XF && j_ok) {
         sc = *reinterpret_cast<const f32x4*>(p.in_scale + ci);
         sh = *reinterpret_cast<const f32x4*>(p.in_shift + ci);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[APASS], rb[4];
     auto gload = [&](int64_t pbase) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t pix = pbase + lpix + 8 * i;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (pix < p_end) {
-                if (co_ok) va = *reinterpret_cast<const f32x4*>(p.dout + pix * p.ldd + co);
-                if (ci_ok) {
-                    const int gx = (int)(pix % p.Wg);
-                    const int64_t t = pix / p.Wg;
-                    const int gy = (int)(t % p.Hg);
-                    const int n = (int)(t / p.Hg);
-                    const int iy = gy * p.in_stride + dy, ix = gx * p.in_stride + dx;
-                    const int fz = (n % p.Kfr) + dz;
-                    if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
-                        (unsigned)fz < (unsigned)p.Kfr) {
-                        const int64_t ipix = ((int64_t)n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride + doff;
-                        vb = *reinterpret_cast<const f32x4*>(p.in + ipix * p.Ci + ci);
-                        if (XF) {
+        for (int i = 0; i < APASS; ++i) {
+            const int64_t pix = pbase + alpix + AROWS * i;
+            const bool ok = pix < p_end && co_ok;
+            const int64_t sel = ok ? pix * p.ldd + co : zd_do;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
+        }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float tt = vb[e] * sc[e] + sh[e];
-                                vb[e] = tt > 0.f ? tt : tt * p.in_slope;
-                            }
-                        }
-                    }
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pix = pbase + blpix + 8 * i;
+            // branch-free gather (zero page for everything out of range), 32-bit pixel decode
+            const bool pin = pix < p_end;
+            const unsigned pu = pin ? (unsigned)pix : 0u;
+            const unsigned t = pu / (unsigned)p.Wg;
+            const int gx = (int)(pu - t * (unsigned)p.Wg);
+            const unsigned n_ = t / (unsigned)p.Hg;
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            const int n = (int)n_;
+            const int iy = gy * p.in_stride + dy, ix = gx * p.in_stride + dx;
+            const int fz = (n % p.Kfr) + dz;
+            const bool bok = pin && j_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+                             (unsigned)fz < (unsigned)p.Kfr;
+            const int64_t o = (int64_t)((n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride) * p.Ci + boff;
+            const int64_t sel = bok ? o : zd_in;
+            f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + sel);
+            if (XF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tt = vb[e] * sc[e] + sh[e];
+                    tt = tt > 0.f ? tt : tt * p.in_slope;
+                    vb[e] = bok ? tt : 0.f;
                 }
             }
-            ra[i] = va;
             rb[i] = vb;
         }
     };
     auto lstore = [&](int buf) {
-        float* a = As + buf * WG_BP * WG_BM;
+        float* a = As + buf * WG_BP * BM;
         float* bb = Bs + buf * WG_BP * WG_BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(a + (lpix + 8 * i) * WG_BM + lc) = ra[i];
-            *reinterpret_cast<f32x4*>(bb + (lpix + 8 * i) * WG_BN + lc) = rb[i];
-        }
+        for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + (alpix + AROWS * i) * BM + alc) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + 8 * i) * WG_BN + blc) = rb[i];
     };
     auto compute = [&](int buf) {
-        const float* a = As + buf * WG_BP * WG_BM + (lane >> 5) * WG_BM + wm * 64 + (lane & 31);
-        const float* bb = Bs + buf * WG_BP * WG_BN + (lane >> 5) * WG_BN + wn * 64 + (lane & 31);
+        const float* a = As + buf * WG_BP * BM + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
+        const float* bb = Bs + buf * WG_BP * WG_BN + (lane >> 5) * WG_BN + wn * TN * 32 + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < WG_BP / 2; ++kk) {
-            float fa[2], fb[2];
+            float fa[TM], fb[TN];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) fa[mi] = a[kk * 2 * WG_BM + mi * 32];
+            for (int mi = 0; mi < TM; ++mi) fa[mi] = a[kk * 2 * BM + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) fb[ni] = bb[kk * 2 * WG_BN + ni * 32];
+            for (int ni = 0; ni < TN; ++ni) fb[ni] = bb[kk * 2 * WG_BN + ni * 32];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
         }
     };
@@ -371,15 +408,15 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
 
     float* out = dst + (int64_t)split * p.Co * Ktot;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int c = tile_c * WG_BN + wn * 64 + ni * 32 + (lane & 31);
-        if (c >= p.Ci) continue;
+    for (int ni = 0; ni < TN; ++ni) {
+        const int jc = tile_j * WG_BN + wn * TN * 32 + ni * 32 + (lane & 31);
+        if (jc >= Ktot) continue;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = tile_m * WG_BM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p.Co) out[(int64_t)row * Ktot + tap * p.Ci + c] = acc[mi][ni][r];
+                const int row = tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.Co) out[(int64_t)row * Ktot + jc] = acc[mi][ni][r];
             }
         }
     }
@@ -397,16 +434,41 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
+int wgrad_bm(const vd_wgrad_desc& d) { return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128); }
+
 int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
     const int64_t P = (int64_t)d.N * d.Hg * d.Wg;
-    const int64_t tiles = vd_cdiv(d.Co, WG_BM) * vd_cdiv(d.Ci, WG_BN) * d.T;
+    const int64_t tiles = vd_cdiv(d.Co, wgrad_bm(d)) * vd_cdiv((int64_t)d.T * d.Ci, WG_BN);
     int64_t s = vd_cdiv(1024, tiles);                 // aim at ~4 blocks per CU
     const int64_t maxs = vd_cdiv(P, 8 * WG_BP);        // >= 8 k-steps per block
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
     return (int)s;
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int lds = 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int64_t tiles = vd_cdiv(d.Co, BM) * vd_cdiv((int64_t)d.T * d.Ci, WG_BN);
+    const float* zp = zero_page();
+    const int64_t zd_in = zp - d.in, zd_do = zp - d.dout;
+    if (d.in_scale)
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, d, dst,
+                           splits, pps, zd_in, zd_do);
+    else
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, d, dst,
+                           splits, pps, zd_in, zd_do);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -508,6 +570,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_igemm: bad Kfr=%d", d->Kfr);
     VD_REQUIRE(d->ldo >= d->Co, "vd_conv_igemm: ldo < Co");
     VD_REQUIRE((int64_t)d->N * d->Hi * d->Wi < (1ll << 31), "vd_conv_igemm: input pixel count overflows int32");
+    VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31), "vd_conv_igemm: GEMM row count overflows int32");
     VD_REQUIRE((d->Hg - 1) * d->out_stride + d->out_oy < d->Ho && (d->Wg - 1) * d->out_stride + d->out_ox < d->Wo,
                "vd_conv_igemm: output grid exceeds output tensor");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
@@ -532,6 +595,8 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_wgrad: bad Kfr");
     VD_REQUIRE(d->ldd >= d->Co && d->ldd % 4 == 0, "vd_conv_wgrad: bad ldd");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_wgrad: in_scale/in_shift mismatch");
+    VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31) && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31),
+               "vd_conv_wgrad: pixel count overflows int32");
     const int splits = wgrad_pick_splits(*d);
     const int64_t need = (splits > 1) ? (int64_t)splits * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && !ws)) {
@@ -541,19 +606,11 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     hipStream_t s = (hipStream_t)stream;
     const int64_t P = (int64_t)d->N * d->Hg * d->Wg;
     int64_t pps = vd_cdiv(vd_cdiv(P, splits), WG_BP) * WG_BP;
-    const int64_t tiles = vd_cdiv(d->Co, WG_BM) * vd_cdiv(d->Ci, WG_BN) * d->T;
-    constexpr int lds = 2 * WG_BP * (WG_BM + WG_BN) * (int)sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
     float* dst = (splits > 1) ? (float*)ws : d->dwp;
-    if (d->in_scale)
-        hipLaunchKernelGGL(k_conv_wgrad<true>, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, *d, dst, splits, pps);
-    else
-        hipLaunchKernelGGL(k_conv_wgrad<false>, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, *d, dst, splits, pps);
+    const int bm = wgrad_bm(*d);
+    if (bm == 32) launch_wgrad<1, 4, 1, 1>(*d, dst, splits, pps, s);
+    else if (bm == 64) launch_wgrad<2, 2, 1, 2>(*d, dst, splits, pps, s);
+    else launch_wgrad<2, 2, 2, 2>(*d, dst, splits, pps, s);
     VD_CHECK_LAUNCH("vd_conv_wgrad");
     if (splits > 1) {
         const int64_t n4 = (int64_t)d->Co * d->T * d->Ci / 4;
