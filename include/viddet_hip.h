@@ -76,6 +76,7 @@ typedef struct {
     const float* in_scale;
     const float* in_shift;
     float   in_slope;
+    int32_t tile;           /* 0 = library heuristic; 1..8 = explicit tile variant (host autotuner) */
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);

@@ -19,6 +19,7 @@
 //   C/D map: acc[r] -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31  => a store instruction writes two
 //   128-B row segments (channel-contiguous NHWC).
 #include "vd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,10 +42,13 @@ struct RowInfo {
 //   body is one straight-line stream.
 // ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, bool XF>
-__global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int AP = BM / 32, BP = BN / 32;
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NT = WM * WN * 64;          // 4 or 8 waves
+    constexpr int RPP = NT / 8;               // tile rows one pass of float4 lanes covers
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile vs loader");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p, const 
     RowInfo ri[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int64_t m = (int64_t)tile_m * BM + lrow + 32 * i;
+        const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
         ri[i].off = 0;
         ri[i].mask = 0u;
         if (m < M) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p, const 
     int64_t boff[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-        const int n = tile_n * BN + lrow + 32 * i;
+        const int n = tile_n * BN + lrow + RPP * i;
         boff[i] = (n < p.Co) ? (int64_t)n * Ktot + lc4 : (int64_t)-1;       // -1: row beyond Co reads zeros
     }
 
@@ -143,10 +147,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const vd_conv_desc p, const 
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int i = 0; i < AP; ++i)
-            *reinterpret_cast<f32x4*>(a + (lrow + 32 * i) * LDS_LD + lc4) = ra[i];
+            *reinterpret_cast<f32x4*>(a + (lrow + RPP * i) * LDS_LD + lc4) = ra[i];
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f32x4*>(b + (lrow + 32 * i) * LDS_LD + lc4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + (lrow + RPP * i) * LDS_LD + lc4) = rb[i];
     };
     auto compute = [&](int buf) {
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
@@ -246,19 +250,31 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
     const int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_w = zp - d.wp;      // element deltas (all pointers are float-aligned)
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(256), lds, s, d, zd_in, zd_w);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w);
     return 0;
 }
 
+// Tile variants (vd_conv_desc.tile; 0 = heuristic).  The host autotunes per launch record at plan-build
+// time (viddet_amd/ops.py autotune_conv): round quantisation (n blocks over 512 slots), how fast a lone
+// block runs and the K depth interact, and no closed-form rule picked the winner for every layer.
 template <bool XF>
 int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
-    const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
-    if (d.Co <= 32) return launch_igemm<4, 1, 1, 1, XF>(d, s);          // 128 x 32
-    if (d.Co <= 64) return launch_igemm<2, 2, 2, 1, XF>(d, s);          // 128 x 64
-    // 128 x 128 unless that leaves most CUs idle
-    const int64_t blk128 = vd_cdiv(M, 128) * vd_cdiv(d.Co, 128);
-    if (blk128 < 384) return launch_igemm<2, 2, 1, 2, XF>(d, s);        //  64 x 128
-    return launch_igemm<2, 2, 2, 2, XF>(d, s);
+    int tile = d.tile;
+    if (tile <= 0 || tile > 8) {
+        if (d.Co <= 32) tile = 7;
+        else if (d.Co <= 64) tile = 6;
+        else tile = 2;
+    }
+    switch (tile) {
+        case 1: return launch_igemm<2, 2, 2, 2, XF>(d, s);   // 128 x 128, 4 waves of 64x64
+        case 2: return launch_igemm<4, 2, 1, 2, XF>(d, s);   // 128 x 128, 8 waves of 32x64
+        case 3: return launch_igemm<2, 4, 2, 1, XF>(d, s);   // 128 x 128, 8 waves of 64x32
+        case 4: return launch_igemm<2, 2, 1, 2, XF>(d, s);   //  64 x 128, 4 waves of 32x64
+        case 5: return launch_igemm<2, 4, 1, 1, XF>(d, s);   //  64 x 128, 8 waves of 32x32
+        case 6: return launch_igemm<2, 2, 2, 1, XF>(d, s);   // 128 x  64, 4 waves of 64x32
+        case 7: return launch_igemm<4, 1, 1, 1, XF>(d, s);   // 128 x  32, 4 waves of 32x32
+        default: return launch_igemm<4, 2, 1, 1, XF>(d, s);  // 128 x  64, 8 waves of 32x32
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
         ("out_stride", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
         ("ldo", C.c_int32), ("ldr", C.c_int32), ("flags", C.c_int32), ("slope", C.c_float),
-        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float), ("tile", C.c_int32),
     ]
 
 

@@ -42,35 +42,50 @@ class Slot:
 
 class Program:
     """A flat replayable list of C-ABI launches; the stream is bound at run time (the last argument of
-    every vd_* entry point), so a program can be replayed eagerly or inside a HIP graph capture."""
+    every vd_* entry point), so a program can be replayed eagerly or inside a HIP graph capture.
+    A record may name a side stream (`stream=`) and python records (`add_py`) carry event record / wait
+    calls, which is how the weight-gradient GEMMs run beside the rest of the backward pass."""
 
     def __init__(self):
         self.recs = []
         self.meta = []          # per-record info (kind, algorithmic flops) for the roofline accounting
         self.keep = []          # descriptor structs / tensors the records point into
+        self.streams = []       # per-record side stream (torch.cuda.Stream) or None = current stream
 
-    def add(self, fname, *args, meta=None):
+    def add(self, fname, *args, meta=None, stream=None):
         fn = getattr(L.load(), fname)
         self.recs.append((fname, fn, args))
         self.meta.append(meta)
+        self.streams.append(stream)
+
+    def add_py(self, fn):
+        self.recs.append((None, fn, ()))
+        self.meta.append(None)
+        self.streams.append(None)
 
     def hold(self, *objs):
         self.keep.extend(objs)
 
     def run(self):
         s = L.stream_ptr()
-        for fname, fn, args in self.recs:
+        for (fname, fn, args), st in zip(self.recs, self.streams):
+            if fname is None:
+                fn()
+                continue
             a = [x.value if isinstance(x, Slot) else x for x in args]
-            rc = fn(*a, s)
+            rc = fn(*a, s if st is None else C.c_void_p(st.cuda_stream))
             if rc != 0:
                 L.check(rc, fname)
 
     def run_timed(self, select):
-        """Replay with a (start, stop) event pair around every record whose entry point is in `select`;
-        events sit on the stream the kernels are launched on.  Returns [(fname, meta, start, stop)]."""
+        """Replay (everything on the current stream, side streams ignored so that each launch is timed alone)
+        with a (start, stop) event pair around every record whose entry point is in `select`.
+        Returns [(fname, meta, start, stop)]."""
         s = L.stream_ptr()
         out = []
         for (fname, fn, args), meta in zip(self.recs, self.meta):
+            if fname is None:
+                continue
             a = [x.value if isinstance(x, Slot) else x for x in args]
             if fname in select:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -83,6 +98,50 @@ class Program:
             if rc != 0:
                 L.check(rc, fname)
         return out
+
+
+_TUNE_CACHE = {}
+
+
+def autotune_program(prog, reps=3):
+    """Pick the fastest k_conv_igemm tile variant for every conv launch of a program (timed in place on the
+    program's own buffers with events on the launch stream; results cached per problem signature).
+    Disabled with VD_AUTOTUNE=0.  Tuning launches only rewrite buffers every real run rewrites first."""
+    import os
+    if os.environ.get("VD_AUTOTUNE", "1") == "0":
+        return
+    lib = L.load()
+    s = L.stream_ptr()
+    for (fname, fn, args) in prog.recs:
+        if fname != 'vd_conv_igemm':
+            continue
+        d = args[0]._obj
+        key = (d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, d.flags, bool(d.in_scale))
+        if key in _TUNE_CACHE:
+            d.tile = _TUNE_CACHE[key]
+            continue
+        if d.Co <= 32:
+            cands = [7]
+        elif d.Co <= 64:
+            cands = [6, 8]
+        else:
+            cands = [1, 2, 3, 4, 5]
+        best, best_t = cands[0], None
+        if len(cands) > 1:
+            for c in cands:
+                d.tile = c
+                L.check(lib.vd_conv_igemm(C.byref(d), s), 'vd_conv_igemm/tune')
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    lib.vd_conv_igemm(C.byref(d), s)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t:
+                    best, best_t = c, t
+        d.tile = best
+        _TUNE_CACHE[key] = best
 
 
 class Parameter:
@@ -252,6 +311,7 @@ class YOLOV3(object):
         self._dgrad_dirty = True
         self._graph_cache = {}
         self.use_graphs = False
+        self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream (see _build_train)
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
@@ -448,6 +508,7 @@ class YOLOV3(object):
                     bufs['d:' + name] = torch.empty_like(bufs[name])
             mx = max(bufs[n.dst].numel() for n in self.conv_nodes)
             bufs['dz'] = torch.empty(mx, device=dev)
+            bufs['dz2'] = torch.empty(mx, device=dev)
             bufs['tmp'] = torch.empty(mx, device=dev)
         self._programs[ck] = bufs
         return bufs
@@ -523,6 +584,7 @@ class YOLOV3(object):
                  o['counts'].data_ptr(), float(self.nms_thresh), int(self.nms_topk), int(self.post_nms),
                  o['ids'].data_ptr(), o['scores'].data_ptr(), o['bboxes'].data_ptr(), o['rows'].data_ptr(),
                  o['overflow'].data_ptr(), 4 * B)
+        autotune_program(prog)
         return prog, bufs, o
 
     def _refresh_fold(self):
@@ -639,7 +701,28 @@ class YOLOV3(object):
         fwd.append(seg)
 
         # ---- backward
+        # The weight-gradient GEMMs (MFMA-bound) run on a side stream beside the main-stream chain
+        # [BN backward (HBM-bound) -> data gradient]: nothing in the backward pass consumes a weight gradient,
+        # so the only edges are  dz ready -> wgrad  (event) and  wgrad done -> dz scratch reuse  (event; the dz
+        # scratch is double-buffered), plus one join before the optimiser.  Tails of one GEMM fill with the other.
         bwd, seg = [], Program()
+        side = torch.cuda.Stream() if self.overlap_wgrad else None
+        ws_w = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if side is not None else ws
+        dz_bufs = [bufs['dz'], bufs['dz2']]
+        dz_free = [None, None]             # event after which dz_bufs[i] may be overwritten
+        n_dz = [0]
+        last_side = [None]
+
+        def ev_record(e, on_side):
+            def f():
+                e.record(side if on_side else torch.cuda.current_stream())
+            return f
+
+        def ev_wait(e, on_side):
+            def f():
+                (side if on_side else torch.cuda.current_stream()).wait_event(e)
+            return f
+
         written = set(self.head_names)     # gradients already produced (the loss kernel wrote d:head*)
         dgrad_packs = []                   # (node, plan, packed weight buffer) re-packed when weights change
 
@@ -685,7 +768,9 @@ class YOLOV3(object):
                         seg.add('vd_bn_apply_leaky', dy.data_ptr(), self._ones(n.cout).data_ptr(),
                                 self._zeros(n.cout).data_ptr(), None, dres.data_ptr(), M, n.cout, 1.0)
                 z = bufs['z:' + n.dst]
-                dz = bufs['dz'][:M * n.cout].view(B, Ho, Wo, n.cout)
+                slot = n_dz[0] % 2
+                n_dz[0] += 1
+                dz = dz_bufs[slot][:M * n.cout].view(B, Ho, Wo, n.cout)
                 seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
                         ws.data_ptr(), ws_bytes)
@@ -695,6 +780,8 @@ class YOLOV3(object):
                     s2 = n.sums2
                     seg = cut(bwd, seg, lambda s2=s2: torch.distributed.all_reduce(s2, group=self.process_group))
                     count = float(M * world)
+                if side is not None and dz_free[slot] is not None:
+                    seg.add_py(ev_wait(dz_free[slot], False))       # the wgrad that read this scratch has finished
                 seg.add('vd_bn_bwd_apply', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
                         dz.data_ptr())
@@ -708,7 +795,19 @@ class YOLOV3(object):
             ops._set_taps(wd_, [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad))
             wd_.Kfr, wd_.splits = 1, 0
             seg.hold(wd_)
-            seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
+            if side is not None:
+                e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
+                seg.add_py(ev_record(e_ready, False))
+                seg.add_py(ev_wait(e_ready, True))
+                seg.add('vd_conv_wgrad', C.byref(wd_), ws_w.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'),
+                        stream=side)
+                seg.add_py(ev_record(e_done, True))
+                seg.hold(e_ready, e_done)
+                if not n.head:
+                    dz_free[slot] = e_done
+                last_side[0] = e_done
+            else:
+                seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
             if n.stem:
                 continue
             # data gradient into d:src
@@ -733,7 +832,13 @@ class YOLOV3(object):
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B))
+        if side is not None and last_side[0] is not None:
+            seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
+        seg.hold(ws_w, side)
         bwd.append(seg)
+        for sg in fwd + bwd:
+            if isinstance(sg, Program):
+                autotune_program(sg)
         return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=dgrad_packs, ws=ws)
 
     @staticmethod
