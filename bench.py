@@ -147,6 +147,19 @@ def main():
         dt = float(t.item())
     fps = world * B * a.steps / dt
 
+    # ---- phase split (one extra step with device syncs between phases; not part of the timed region)
+    phases = None
+    if rank == 0 and train:
+        def timed(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t) * 1e3, 3)
+        phases = {"fwd_loss_ms": timed(lambda: net(x, gt, *tgd)), "bwd_ms": timed(net.backward),
+                  "allreduce_ms": timed(net.allreduce_grads),
+                  "sgd_ms": timed(lambda: net.sgd_step(lr, mom, wd, batch_size=B * world))}
+
     # ---- roofline of the dominant kernel (k_conv_igemm: forward + data-gradient convs), measured live with
     # events on the launch stream over one more step
     roof = None
@@ -212,7 +225,7 @@ def main():
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, fp32" % (B, S, S)),
                        "classes": C, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "syncbn": a.syncbn, "score_filter": (None if train else pass_info)},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": extra,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": extra, "phases": phases,
         }
         if gflop:
             out["model_tflops"] = round(fps * gflop / 1e3, 2)

@@ -127,6 +127,9 @@ class Net:
         self.P, self.C = P, num_class
         self.G = {}            # parameter gradients (training)
         self.new_running = {}  # running stats after a training forward
+        self.vars = {}         # cell name -> output Var (its .g after backward = dL/d(cell output); debugging aid)
+        self.pre = {}          # cell name -> BN output before LeakyReLU (training forward)
+        self.mask_override = {}   # cell name -> bool (N,C,H,W): LeakyReLU branch decisions to use (see ops.leaky)
 
     # ---- _conv2d cell (layers.py:63-70)
     def cell(self, name, x, k, stride, train, residual=None):
@@ -146,7 +149,9 @@ class Net:
         u, mean, var = R.bn_train(z, gamma, beta)
         self.new_running[name + ".1.running_mean"] = R.bn_running_update(P[name + ".1.running_mean"], mean)
         self.new_running[name + ".1.running_var"] = R.bn_running_update(P[name + ".1.running_var"], var)
-        y = R.leaky(u)
+        self.pre[name] = u
+        pos = self.mask_override.get(name)
+        y = R.leaky(u, pos=pos)
         if residual is not None:
             y = y + residual.v
         parents = (x,) if residual is None else (x, residual)
@@ -154,7 +159,7 @@ class Net:
         def bw(g):
             if residual is not None:
                 residual.acc(g)
-            du = R.leaky_backward(u, g)
+            du = R.leaky_backward(u, g, pos=pos)
             dz, dgamma, dbeta = R.bn_train_backward(z, gamma, mean, var, du)
             dx, dw = R.conv2d_backward(x.v, w, dz, stride, pad)
             self.G[name + ".0.weight"] = dw
@@ -162,7 +167,9 @@ class Net:
             self.G[name + ".1.beta"] = dbeta
             x.acc(dx)
 
-        return Var(y, parents, bw)
+        out = Var(y, parents, bw)
+        self.vars[name] = out
+        return out
 
     def head(self, i, x, train):
         w = self.P["yolo_outputs.%d.prediction.weight" % i]

@@ -78,6 +78,25 @@ def conv3d(x, w, pad_d, pad, stride=1):
     return out.reshape(n, do, o, ho, wo).transpose(0, 2, 1, 3, 4)
 
 
+def conv3d_backward(x, w, dy, pad_d, pad, stride=1):
+    """Gradients of conv3d wrt x and w (temporal stride 1)."""
+    n, c, d, h, wd = x.shape
+    o, _, kd, kh, kw = w.shape
+    do = d + 2 * pad_d - kd + 1
+    xp = np.zeros((n, c, d + 2 * pad_d, h, wd), dtype=x.dtype)
+    xp[:, :, pad_d:pad_d + d] = x
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w)
+    ho, wo = dy.shape[3], dy.shape[4]
+    dy2 = dy.transpose(0, 2, 1, 3, 4).reshape(n * do, o, ho, wo)
+    for kz in range(kd):
+        f2 = xp[:, :, kz:kz + do].transpose(0, 2, 1, 3, 4).reshape(n * do, c, h, wd)
+        dx2, dwk = conv2d_backward(f2, w[:, :, kz], dy2, stride, pad)
+        dw[:, :, kz] = dwk
+        dxp[:, :, kz:kz + do] += dx2.reshape(n, do, c, h, wd).transpose(0, 2, 1, 3, 4)
+    return dxp[:, :, pad_d:pad_d + d], dw
+
+
 # ---------------------------------------------------------------------------------------------
 # models/definitions/layers.py:68  BatchNorm(epsilon=1e-5, momentum=0.9)   (SURVEY A.4)
 # ---------------------------------------------------------------------------------------------
@@ -114,12 +133,16 @@ def bn_train_backward(x, gamma, mean, var, dy, eps=1e-5):
 
 
 # models/definitions/layers.py:69  nn.LeakyReLU(0.1)
-def leaky(x, slope=0.1):
-    return np.where(x > 0, x, x * slope)
+# `pos` (optional) = externally supplied branch decisions.  The parity tests pass the DEVICE's own x>0 decisions
+# so that an element whose pre-activation is ~1e-7 (sign decided by fp32 vs fp64 rounding; about one such
+# element per training step of the whole net) does not turn into a spurious 1-2 % gradient difference.  The
+# tests assert that supplied and natural decisions differ only where |x| < 1e-5.
+def leaky(x, slope=0.1, pos=None):
+    return np.where((x > 0) if pos is None else pos, x, x * slope)
 
 
-def leaky_backward(x, dy, slope=0.1):
-    return np.where(x > 0, dy, dy * slope)
+def leaky_backward(x, dy, slope=0.1, pos=None):
+    return np.where((x > 0) if pos is None else pos, dy, dy * slope)
 
 
 # models/definitions/layers.py:11-20  _upsample: repeat along W then H

@@ -197,3 +197,21 @@ def test_stem_im2col_conv_and_wgrad():
     got = dwp.cpu().numpy()[:, :27].reshape(co, 3, 3, 3).transpose(0, 3, 1, 2)
     assert maxdiff(got, dw_ref) < TOL * np.sqrt(n * h * w)
     assert float(dwp[:, 27:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 128, 3, 1, 1), (6, 128, 8, 8, 256, 3, 1, 1), (3, 32, 13, 11, 96, 1, 1, 0),
+                                   (2, 64, 17, 15, 160, 3, 2, 1)])
+def test_conv_fwd_every_tile_variant(tile, shape):
+    """Every k_conv_igemm tile variant the autotuner may pick (vd_conv_desc.tile = 1..8) on ragged shapes."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = shape
+    rng, x, wt = _mk(n, ci, h, w, co, k, 40 + tile)
+    res = rng.standard_normal((n, co, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1))
+    ref = R.conv2d(x, wt, s, p) + res
+    co_pad = ops.round_up(co, 32)
+    out = torch.full((n, ref.shape[2], ref.shape[3], co_pad), 7.0, device="cuda")
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co_pad), out, k=k, stride=s, pad=p, Co=co_pad, ldo=co_pad,
+                 residual=nchw_to_dev_nhwc(res, co_pad), tile=tile)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL

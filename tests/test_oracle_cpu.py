@@ -219,3 +219,39 @@ def test_voc_map_ladder():
     # class a: matches by score: TP, FP, TP, (dup -> FP) ; recall ladder 1/2 @ p=1, 2/2 @ p=2/3 -> AP = .5*1 + .5*(2/3)
     assert np.isclose(aps[0], 0.5 + 0.5 * (2 / 3)) and np.isclose(aps[1], 1.0)
     assert np.isclose(mean, (aps[0] + 1.0) / 2)
+
+
+def test_conv3d_backward_vs_torch():
+    rng = np.random.default_rng(3)
+    x, w = rng.standard_normal((2, 3, 3, 5, 6)), rng.standard_normal((4, 3, 3, 3, 3))
+    xt, wt = T(x).requires_grad_(), T(w).requires_grad_()
+    y = F.conv3d(xt, wt, padding=(1, 1, 1))
+    dy = rng.standard_normal(tuple(y.shape))
+    y.backward(T(dy))
+    dx, dw = R.conv3d_backward(x, w, dy, 1, 1)
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-10) and np.allclose(dw, wt.grad.numpy(), atol=1e-10)
+    # (3,1,1) temporal-only kernel of the 2+1-D cell
+    w2 = rng.standard_normal((4, 3, 3, 1, 1))
+    w2t = T(w2).requires_grad_()
+    xt2 = T(x).requires_grad_()
+    y2 = F.conv3d(xt2, w2t, padding=(1, 0, 0))
+    dy2 = rng.standard_normal(tuple(y2.shape))
+    y2.backward(T(dy2))
+    assert np.allclose(R.conv3d(x, w2, 1, 0), y2.detach().numpy(), atol=1e-10)
+    dx2, dw2 = R.conv3d_backward(x, w2, dy2, 1, 0)
+    assert np.allclose(dx2, xt2.grad.numpy(), atol=1e-10) and np.allclose(dw2, w2t.grad.numpy(), atol=1e-10)
+
+
+def test_temporal_oracle_shapes_and_pool_backward():
+    from oracle import net_temporal as OT
+    c, K = 2, 3
+    for jp, bct in (("early", "2"), ("late", "2"), ("late", "3"), ("late", "21")):
+        P = OT.init_params(c, K, jp, bct, seed=1)
+        net = OT.TemporalNet(P, c, K, "max", jp, bct)
+        x = np.random.default_rng(0).standard_normal((1, K, 3, 32, 32))
+        heads = net.features(x, train=False)
+        assert [h.v.shape for h in heads] == [(1, 21, 1, 1), (1, 21, 2, 2), (1, 21, 4, 4)]
+    v = OT.Var(np.array([[[[1.0]]], [[[3.0]]], [[[2.0]]]]))          # K=3 frames of one window
+    y = net.pool(v)
+    OT.backward([(y, np.array([[[[5.0]]]]))])
+    assert v.g.ravel().tolist() == [0.0, 5.0, 0.0]

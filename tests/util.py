@@ -26,3 +26,30 @@ def dev_nhwc_to_nchw(t, c=None):
 
 def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def device_leaky_masks(net, bufs):
+    """LeakyReLU branch decisions the device took in its last TRAINING forward: sign of z*scale+shift per conv
+    cell, evaluated in fp32 exactly as the kernels do, as {cell name: bool (N,C,H,W)}."""
+    from viddet_amd.model import ConvNode
+    out = {}
+    for n in net.nodes:
+        if isinstance(n, ConvNode) and n.bn:
+            z = bufs['z:' + n.dst].cpu().numpy()
+            # the kernels evaluate v*scale+shift as ONE fma (hipcc contracts): its sign is the sign of the exact
+            # value, which float64 arithmetic on the fp32 operands reproduces
+            u = z.astype(np.float64) * n.b_scale.cpu().numpy().astype(np.float64) + \
+                n.b_shift.cpu().numpy().astype(np.float64)
+            out[n.name] = np.moveaxis(u > 0, -1, 1)
+    return out
+
+
+def check_masks_differ_only_at_ties(onet_natural_pre, masks, band=2e-4):
+    """The supplied decisions may differ from the oracle's own only where the oracle's |pre-activation| is tiny."""
+    nflip = 0
+    for name, u in onet_natural_pre.items():
+        diff = (u > 0) != masks[name]
+        if diff.any():
+            assert np.abs(u[diff]).max() < band, (name, float(np.abs(u[diff]).max()))
+            nflip += int(diff.sum())
+    return nflip

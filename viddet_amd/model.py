@@ -207,21 +207,40 @@ class ParameterDict(OrderedDict):
 
 
 class ConvNode:
-    def __init__(self, name, src, dst, cin, cout, k, stride, div_in, bn=True, residual=None, stem=False, head=False):
+    def __init__(self, name, src, dst, cin, cout, k, stride, div_in, bn=True, residual=None, stem=False, head=False,
+                 kd=1, fr=1):
         self.name, self.src, self.dst = name, src, dst
         self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
         self.pad = k // 2
+        self.kd, self.pad_d = kd, kd // 2          # temporal kernel depth (Conv3D over the K frames of a window)
+        self.fr = fr                               # frames per sample carried by this node's tensors (K or 1)
         self.div_in = div_in                       # input spatial = H / div_in
         self.div_out = div_in * stride
         self.bn, self.residual, self.stem, self.head = bn, residual, stem, head
         self.co_pad = round_up(cout, 32) if head else cout
         self.ci_eff = 32 if stem else cin           # stem runs as 1x1 over the 32-wide im2col
-        self.T = 1 if stem else k * k
+        self.T = 1 if stem else kd * k * k
+
+    def taps(self):
+        return [(0, 0, 0)] if self.stem else fwd_taps(self.k, self.pad, self.kd, self.pad_d)
+
+    def weight_shape(self):
+        if self.kd > 1 or getattr(self, 'conv3d', False):
+            return (self.cout, self.cin, self.kd, self.k, self.k)
+        return (self.cout, self.cin, self.k, self.k)
 
 
 class UpcatNode:
-    def __init__(self, name, up, route, dst, cu, cr, div_out):
+    def __init__(self, name, up, route, dst, cu, cr, div_out, fr=1):
         self.name, self.up, self.route, self.dst, self.cu, self.cr, self.div_out = name, up, route, dst, cu, cr, div_out
+        self.fr = fr
+
+
+class PoolNode:
+    """TemporalPooling over the K frames of a window (layers.py:161-205): (B*K, h, w, C) -> (B, h, w, C)."""
+
+    def __init__(self, name, src, dst, K, type_):
+        self.name, self.src, self.dst, self.K, self.type = name, src, dst, K, 0 if type_ == 'max' else 1
 
 
 def _feature_name(f):
@@ -232,60 +251,113 @@ def _feature_name(f):
     return "stages.2.%d" % (f - 24)
 
 
-def build_graph(num_class):
-    """Node list of YOLOV3T(k=1) over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258)."""
-    nodes, tensors = [], OrderedDict()     # tensors[name] = (channels, div, pitch)
+def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2'):
+    """Node list of YOLOV3T over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258;
+    yolo3.py:1003-1054 wiring, :1095-1177 forward).  k>1: the backbone is TimeDistributed (K frames folded
+    into the batch, layers.py:241-250); 'early' joins pool each stage output over K, 'late' joins keep K frames
+    through the neck (2-D blocks per frame, or 3-D / 2+1-D convs across the K axis, yolo3.py:229-262) and pool
+    the tips right before the prediction convs (:1134-1138)."""
+    nodes, tensors = [], OrderedDict()     # tensors[name] = (channels, div, pitch, frames)
+    K = k if k and k > 1 else 1
+    late = K > 1 and k_join_pos == 'late'
+    td = ".model" if K > 1 else ""         # TimeDistributed registers its child as `.model`
 
-    def T(name, c, div, ld=None):
-        tensors[name] = (c, div, c if ld is None else ld)
+    def T(name, c, div, ld=None, fr=1):
+        tensors[name] = (c, div, c if ld is None else ld, fr)
         return name
 
-    T('in', 3, 1)
-    f = 0
-    cur = T('f0', 32, 1)
-    nodes.append(ConvNode(_feature_name(0), 'in', cur, 3, 32, 3, 1, 1, stem=True))
+    def sname(f):
+        nm = _feature_name(f)
+        if K > 1:
+            head, idx = nm.rsplit(".", 1)
+            nm = "%s.model.%s" % (head, idx)
+        return nm
+
+    T('in', 3, 1, fr=K)
+    cur = T('f0', 32, 1, fr=K)
+    nodes.append(ConvNode(sname(0), 'in', cur, 3, 32, 3, 1, 1, stem=True, fr=K))
     f = 1
     div = 1
     routes = []
     for nlayer, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
-        nxt = T('f%d' % f, ch, div * 2)
-        nodes.append(ConvNode(_feature_name(f), cur, nxt, ch // 2, ch, 3, 2, div))
+        nxt = T('f%d' % f, ch, div * 2, fr=K)
+        nodes.append(ConvNode(sname(f), cur, nxt, ch // 2, ch, 3, 2, div, fr=K))
         cur, div, f = nxt, div * 2, f + 1
         for _ in range(nlayer):
-            mid = T('f%d.m' % f, ch // 2, div)
-            nxt = T('f%d' % f, ch, div)
-            nm = _feature_name(f)
-            nodes.append(ConvNode(nm + ".body.0", cur, mid, ch, ch // 2, 1, 1, div))
-            nodes.append(ConvNode(nm + ".body.1", mid, nxt, ch // 2, ch, 3, 1, div, residual=cur))
+            mid = T('f%d.m' % f, ch // 2, div, fr=K)
+            nxt = T('f%d' % f, ch, div, fr=K)
+            nm = sname(f)
+            nodes.append(ConvNode(nm + ".body.0", cur, mid, ch, ch // 2, 1, 1, div, fr=K))
+            nodes.append(ConvNode(nm + ".body.1", mid, nxt, ch // 2, ch, 3, 1, div, residual=cur, fr=K))
             cur, f = nxt, f + 1
         if f in (15, 24, 29):
             routes.append(cur)
+    nfr = K if late else 1                 # frames carried through the neck
+    if K > 1 and not late:                 # 'early' join (yolo3.py:1107-1124): pool every route over K
+        pooled = []
+        for i, r in enumerate(routes):
+            c_, d_ = tensors[r][0], tensors[r][1]
+            pr = T('route%d.pool' % i, c_, d_)
+            nodes.append(PoolNode('pool.route%d' % i, r, pr, K, k_join_type))
+            pooled.append(pr)
+        routes = pooled
     # neck + heads, deepest first (yolo3.py:1013-1054, 1126-1177)
     A = 3 * (5 + num_class)
     x, xc = routes[2], 1024
     heads = []
+    conv3 = block_conv_type in ('3', '21')
     for i, c in enumerate([512, 256, 128]):
         d = 32 >> i
-        pre = "yolo_blocks.%d" % i
+        if conv3:
+            pre, cell = "yolo_blocks.%d" % i, ".conv"           # Conv wrapper registers `.conv` (layers.py:135-158)
+        elif late:
+            pre, cell = "yolo_blocks.%d.model" % i, ""           # TimeDistributed(block)
+        else:
+            pre, cell = "yolo_blocks.%d" % i, ""
+
+        def add_cell(name, src, dst_name, cin, cout, ksz):
+            """one Conv+BN+LeakyReLU cell of the detection block; 3x3 cells become 3x3x3 ('3') or
+            (1,3,3)+(3,1,1) ('21') across the K frames when block_conv_type asks for it"""
+            if conv3 and ksz == 3 and block_conv_type == '3':
+                dst = T(dst_name, cout, d, fr=nfr)
+                nodes.append(ConvNode(name + cell, src, dst, cin, cout, 3, 1, d, kd=3, fr=nfr))
+                return dst
+            if conv3 and ksz == 3:       # R(2+1)D: spatial then temporal, each with BN + LeakyReLU (layers.py:82-89)
+                mid = T(dst_name + ".s", cout, d, fr=nfr)
+                n1 = ConvNode(name + cell + ".0", src, mid, cin, cout, 3, 1, d, fr=nfr)
+                n1.conv3d = True
+                nodes.append(n1)
+                dst = T(dst_name, cout, d, fr=nfr)
+                n2 = ConvNode(name + cell + ".1", mid, dst, cout, cout, 1, 1, d, kd=3, fr=nfr)
+                nodes.append(n2)
+                return dst
+            dst = T(dst_name, cout, d, fr=nfr)
+            n1 = ConvNode(name + cell, src, dst, cin, cout, ksz, 1, d, fr=nfr)
+            n1.conv3d = conv3              # 1x1x1 Conv3D: same arithmetic as the per-frame 1x1, 5-D weight
+            nodes.append(n1)
+            return dst
+
         for j in range(5):
             cout = c if j % 2 == 0 else 2 * c
-            k = 1 if j % 2 == 0 else 3
-            nxt = T('n%d.b%d' % (i, j), cout, d)
-            nodes.append(ConvNode("%s.body.%d" % (pre, j), x, nxt, xc, cout, k, 1, d))
-            x, xc = nxt, cout
+            x = add_cell("%s.body.%d" % (pre, j), x, 'n%d.b%d' % (i, j), xc, cout, 1 if j % 2 == 0 else 3)
+            xc = cout
         route = x
-        tip = T('n%d.tip' % i, 2 * c, d)
-        nodes.append(ConvNode(pre + ".tip", route, tip, c, 2 * c, 3, 1, d))
+        tip = add_cell(pre + ".tip", route, 'n%d.tip' % i, c, 2 * c, 3)
+        if late:                                                # yolo3.py:1134-1138: pool the tip over K
+            ptip = T('n%d.tip.pool' % i, 2 * c, d)
+            nodes.append(PoolNode('pool.tip%d' % i, tip, ptip, K, k_join_type))
+            tip = ptip
         hd = T('head%d' % i, A, d, round_up(A, 32))
         nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, 2 * c, A, 1, 1, d, bn=False, head=True))
         heads.append(hd)
         if i < 2:
-            tr = T('n%d.tr' % i, c // 2, d)
-            nodes.append(ConvNode("transitions.%d" % i, route, tr, c, c // 2, 1, 1, d))
+            tr = T('n%d.tr' % i, c // 2, d, fr=nfr)
+            nodes.append(ConvNode("transitions.%d%s" % (i, ".model" if late else ""), route, tr, c, c // 2, 1, 1, d,
+                                  fr=nfr))
             rt = routes[1 - i]
             rc = tensors[rt][0]
-            cat = T('n%d.cat' % i, c // 2 + rc, d // 2)
-            nodes.append(UpcatNode("upcat.%d" % i, tr, rt, cat, c // 2, rc, d // 2))
+            cat = T('n%d.cat' % i, c // 2 + rc, d // 2, fr=nfr)
+            nodes.append(UpcatNode("upcat.%d" % i, tr, rt, cat, c // 2, rc, d // 2, fr=nfr))
             x, xc = cat, c // 2 + rc
     return nodes, tensors, heads
 
@@ -295,8 +367,11 @@ class YOLOV3(object):
     collect_params, save/load_parameters, hybridize, initialize).  k=1 (YOLOV3T with k=1 == YOLOV3)."""
 
     def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, ignore_iou_thresh=0.7,
-                 device="cuda", syncbn_scope=None, process_group=None):
+                 device="cuda", syncbn_scope=None, process_group=None, k=1, k_join_type=None, k_join_pos=None,
+                 block_conv_type='2'):
         self._classes = list(classes)
+        self._k = k if k and k > 1 else 1
+        self._k_join_type, self._k_join_pos, self._block_conv_type = k_join_type, k_join_pos, block_conv_type
         self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
         self._ignore_iou_thresh = ignore_iou_thresh
         self._label_smooth = False
@@ -311,13 +386,15 @@ class YOLOV3(object):
         self._dgrad_dirty = True
         self._graph_cache = {}
         self.use_graphs = False
-        self.overlap_wgrad = True      # weight-gradient GEMMs on a side stream (see _build_train)
+        import os as _os
+        self.overlap_wgrad = _os.environ.get('VD_OVERLAP', '1') != '0'   # wgrad GEMMs on a side stream (_build_train)
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
     def _build(self, num_class):
         self.num_class = num_class
-        self.nodes, self.tensors, self.head_names = build_graph(num_class)
+        self.nodes, self.tensors, self.head_names = build_graph(num_class, self._k, self._k_join_type,
+                                                                self._k_join_pos, self._block_conv_type)
         self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
         # arena layout: [conv weights (fwd-packed) | bn gamma, beta, head bias]  -> wd / no_wd ranges
         off = 0
@@ -382,7 +459,7 @@ class YOLOV3(object):
                 reg(n.name + ".bias", (n.cout,), 'vector', n, n.bias, n.gbias)
             else:
                 kind = 'stem_weight' if n.stem else 'conv_weight'
-                reg(n.name + ".0.weight", (n.cout, n.cin, n.k, n.k), kind, n, wv, gv)
+                reg(n.name + ".0.weight", n.weight_shape(), kind, n, wv, gv)
                 n.gamma = self.weights[n.gamma_off:n.gamma_off + n.cout]
                 n.beta = self.weights[n.beta_off:n.beta_off + n.cout]
                 n.ggamma = self.grads[n.gamma_off:n.gamma_off + n.cout]
@@ -423,7 +500,7 @@ class YOLOV3(object):
                 if init == 'uniform':
                     v = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.07
                 else:
-                    fan = p.shape[1] * p.shape[2] * p.shape[3]
+                    fan = int(np.prod(p.shape[1:]))
                     v = torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan)
                 p.set_data(v)
             elif name.endswith('gamma') or name.endswith('running_var'):
@@ -493,13 +570,16 @@ class YOLOV3(object):
             return self._programs[ck]
         dev = self.device
         bufs = {}
-        for name, (c, div, ld) in self.tensors.items():
+        for name, (c, div, ld, fr) in self.tensors.items():
             if name == 'in':
-                bufs['in'] = torch.empty(B, 3, H, W, device=dev)
+                bufs['in'] = torch.empty(B * fr, 3, H, W, device=dev)      # (B,K,3,H,W) folded: frame n = b*K + k
                 continue
-            bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
-        bufs['col'] = torch.empty(B, H, W, 32, device=dev)
+            bufs[name] = torch.empty(B * fr, H // div, W // div, ld, device=dev)
+        bufs['col'] = torch.empty(B * self._k, H, W, 32, device=dev)
         if train:
+            for n in self.nodes:
+                if isinstance(n, PoolNode) and n.type == 0:
+                    bufs['am:' + n.dst] = torch.empty(bufs[n.dst].shape, dtype=torch.int32, device=dev)
             for n in self.conv_nodes:
                 if n.bn:
                     bufs['z:' + n.dst] = torch.empty_like(bufs[n.dst])
@@ -525,11 +605,10 @@ class YOLOV3(object):
         Hi, Wi = H // n.div_in, W // n.div_in
         Ho, Wo = H // n.div_out, W // n.div_out
         d.in_, d.wp, d.out = x.data_ptr(), n.wp.data_ptr(), out.data_ptr()
-        d.N, d.Hi, d.Wi, d.Ci = B, Hi, Wi, n.ci_eff
+        d.N, d.Hi, d.Wi, d.Ci = B * n.fr, Hi, Wi, n.ci_eff
         d.Hg, d.Wg, d.in_stride = Ho, Wo, n.stride
-        taps = [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad)
-        ops._set_taps(d, taps)
-        d.Kfr = 1
+        ops._set_taps(d, n.taps())
+        d.Kfr = n.fr if n.kd > 1 else 1
         d.Ho, d.Wo, d.Co = Ho, Wo, n.co_pad
         d.out_stride, d.out_oy, d.out_ox = 1, 0, 0
         d.ldo = d.ldr = n.co_pad
@@ -549,12 +628,16 @@ class YOLOV3(object):
     def _build_infer(self, B, H, W):
         bufs = self._buffers('infer', B, H, W, False)
         prog = Program()
-        prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
+        prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
-                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
+                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B * n.fr,
                          o.shape[1], o.shape[2], n.cu, n.cr)
+                continue
+            if isinstance(n, PoolNode):
+                o = bufs[n.dst]
+                prog.add('vd_temporal_pool', bufs[n.src].data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
                 continue
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
@@ -597,14 +680,14 @@ class YOLOV3(object):
 
     # ------------------------------------------------------------------ inference
     def _forward_infer(self, x):
-        B, _, H, W = x.shape
+        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
         assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
         key = ('infer', B, H, W)
         if key not in self._programs:
             self._programs[key] = self._build_infer(B, H, W)
         prog, bufs, o = self._programs[key]
         self._refresh_fold()
-        bufs['in'].copy_(x)
+        bufs['in'].copy_(x.reshape(bufs['in'].shape))
         if self.use_graphs:
             g = self._graph_cache.get(key)
             if g is None:
@@ -639,10 +722,11 @@ class YOLOV3(object):
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
             if n.stem:
-                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B, Hi, Wi, 32, Ho, Wo, n.co_pad, 1, 1, 0))
+                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B * n.fr, Hi, Wi, 32, Ho, Wo, n.co_pad, 1, 1, 0))
             else:
-                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.k, n.stride, n.pad))
-            ws_bytes = max(ws_bytes, ops.bn_stats_ws_bytes(B * Ho * Wo, n.co_pad))
+                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B * n.fr, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.k, n.stride,
+                                                            n.pad, n.kd, n.pad_d))
+            ws_bytes = max(ws_bytes, ops.bn_stats_ws_bytes(B * n.fr * Ho * Wo, n.co_pad))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -650,7 +734,7 @@ class YOLOV3(object):
 
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
-        seg.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
+        seg.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
 
         def cut(segments, p, fn):
             segments.append(p)
@@ -660,11 +744,16 @@ class YOLOV3(object):
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
-                seg.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B, o.shape[1],
-                        o.shape[2], n.cu, n.cr)
+                seg.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B * n.fr,
+                        o.shape[1], o.shape[2], n.cu, n.cr)
+                continue
+            if isinstance(n, PoolNode):
+                o = bufs[n.dst]
+                am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
+                seg.add('vd_temporal_pool', bufs[n.src].data_ptr(), o.data_ptr(), am, B, n.K, o[0].numel(), n.type)
                 continue
             Ho, Wo = H // n.div_out, W // n.div_out
-            M = B * Ho * Wo
+            M = B * n.fr * Ho * Wo
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
                 seg.hold(d)
@@ -741,16 +830,28 @@ class YOLOV3(object):
                 assert not acc_u
                 if acc_r:
                     tmp = bufs['tmp'][:drt.numel()]
-                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), tmp.data_ptr(), B, dout.shape[1],
-                            dout.shape[2], n.cu, n.cr)
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), tmp.data_ptr(), B * n.fr,
+                            dout.shape[1], dout.shape[2], n.cu, n.cr)
                     seg.add('vd_add', drt.data_ptr(), tmp.data_ptr(), drt.data_ptr(), drt.numel())
                 else:
-                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), drt.data_ptr(), B, dout.shape[1],
-                            dout.shape[2], n.cu, n.cr)
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), drt.data_ptr(), B * n.fr,
+                            dout.shape[1], dout.shape[2], n.cu, n.cr)
+                continue
+            if isinstance(n, PoolNode):
+                dout = bufs['d:' + n.dst]
+                assert n.dst in written, n.name
+                dsrc, acc = grad_into(n.src, 0)
+                am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
+                if acc:
+                    tmp = bufs['tmp'][:dsrc.numel()]
+                    seg.add('vd_temporal_pool_bwd', dout.data_ptr(), am, tmp.data_ptr(), B, n.K, dout[0].numel(), n.type)
+                    seg.add('vd_add', dsrc.data_ptr(), tmp.data_ptr(), dsrc.data_ptr(), dsrc.numel())
+                else:
+                    seg.add('vd_temporal_pool_bwd', dout.data_ptr(), am, dsrc.data_ptr(), B, n.K, dout[0].numel(), n.type)
                 continue
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
-            M = B * Ho * Wo
+            M = B * n.fr * Ho * Wo
             dy = bufs['d:' + n.dst]
             assert n.dst in written, n.name
             if n.head:
@@ -770,7 +871,7 @@ class YOLOV3(object):
                 z = bufs['z:' + n.dst]
                 slot = n_dz[0] % 2
                 n_dz[0] += 1
-                dz = dz_bufs[slot][:M * n.cout].view(B, Ho, Wo, n.cout)
+                dz = dz_bufs[slot][:M * n.cout].view(B * n.fr, Ho, Wo, n.cout)
                 seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
                         ws.data_ptr(), ws_bytes)
@@ -789,11 +890,11 @@ class YOLOV3(object):
             wd_ = WgradDesc()
             xin = bufs['col'] if n.stem else bufs[n.src]
             wd_.in_, wd_.dout, wd_.dwp = xin.data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
-            wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B, Hi, Wi, n.ci_eff
+            wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B * n.fr, Hi, Wi, n.ci_eff
             wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, n.co_pad
             wd_.in_stride = n.stride
-            ops._set_taps(wd_, [(0, 0, 0)] if n.stem else fwd_taps(n.k, n.pad))
-            wd_.Kfr, wd_.splits = 1, 0
+            ops._set_taps(wd_, n.taps())
+            wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
             seg.hold(wd_)
             if side is not None:
                 e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
@@ -812,16 +913,16 @@ class YOLOV3(object):
                 continue
             # data gradient into d:src
             dsrc, acc = grad_into(n.src, 0)
-            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi):
+            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, n.kd, n.pad_d):
                 assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
                 wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
                 dgrad_packs.append((n, plan, wpk))
                 d = ConvDesc()
                 d.in_, d.wp, d.out = dz.data_ptr(), wpk.data_ptr(), dsrc.data_ptr()
-                d.N, d.Hi, d.Wi, d.Ci = B, Ho, Wo, n.co_pad
+                d.N, d.Hi, d.Wi, d.Ci = B * n.fr, Ho, Wo, n.co_pad
                 d.Hg, d.Wg, d.in_stride = plan['Hg'], plan['Wg'], 1
                 ops._set_taps(d, plan['taps'])
-                d.Kfr = 1
+                d.Kfr = n.fr if n.kd > 1 else 1
                 d.Ho, d.Wo, d.Co = Hi, Wi, n.cin
                 d.out_stride, d.out_oy, d.out_ox = n.stride, plan['py'], plan['px']
                 d.ldo = d.ldr = n.cin
@@ -831,7 +932,7 @@ class YOLOV3(object):
                 seg.hold(d, wpk)
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
-                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B))
+                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr))
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
         seg.hold(ws_w, side)
@@ -845,7 +946,7 @@ class YOLOV3(object):
     def _flops(n, B, H, W, kind):
         """Algorithmic FLOPs of one conv launch: 2*Cin*Cout*k*k*Ho*Wo per image."""
         return dict(kind=kind, node=n.name, k=n.k, stride=n.stride,
-                    flops=2.0 * n.cin * n.cout * n.k * n.k * (H // n.div_out) * (W // n.div_out) * B)
+                    flops=2.0 * n.cin * n.cout * n.kd * n.k * n.k * (H // n.div_out) * (W // n.div_out) * B * n.fr)
 
     def _ones(self, c):
         if not hasattr(self, '_const'):
@@ -860,7 +961,7 @@ class YOLOV3(object):
         if not self._dgrad_dirty:
             return
         for n, plan, wpk in tp['dgrad_packs']:
-            ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=1, kh=n.k, kw=n.k,
+            ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
                                   tap_ids=plan['tap_ids'], src_packed=True)
         self._dgrad_dirty = False
 
@@ -873,7 +974,7 @@ class YOLOV3(object):
                 s()
 
     def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
-        B, _, H, W = x.shape
+        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
         key = ('train', B, H, W)
         if key not in self._programs:
             self._programs[key] = self._build_train(B, H, W)
@@ -886,7 +987,7 @@ class YOLOV3(object):
         s['obj'].value, s['ctr'].value, s['scl'].value = obj.data_ptr(), ctr.data_ptr(), scl.data_ptr()
         s['wgt'].value, s['cls'].value = wgt.data_ptr(), cls.data_ptr()
         s['smooth'].value = 1 if self._label_smooth else 0
-        tp['bufs']['in'].copy_(x)
+        tp['bufs']['in'].copy_(x.reshape(tp['bufs']['in'].shape))
         self._run_segments(tp['fwd'])
         self._fold_dirty = True            # running stats moved
         self._last_train = tp
@@ -902,7 +1003,10 @@ class YOLOV3(object):
 
     # ------------------------------------------------------------------ call protocol
     def __call__(self, x, *args):
-        if x.dim() != 4 or x.shape[1] != 3:
+        if self._k > 1:
+            if x.dim() != 5 or x.shape[1] != self._k or x.shape[2] != 3:
+                raise ValueError("expected a (B,%d,3,H,W) window batch, got %s" % (self._k, tuple(x.shape)))
+        elif x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected a (B,3,H,W) batch, got %s" % (tuple(x.shape),))
         if len(args) == 0:
             return self._forward_infer(x)
@@ -951,15 +1055,27 @@ class YOLOV3(object):
 
 def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs=None, freeze_base=False,
                     k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', **kwargs):
-    """wrappers.py:9-110.  norm_layer='syncbn' (the reference passes SyncBatchNorm) selects the SyncBN collective."""
-    if k not in (None, 1):
-        raise NotImplementedError("temporal windows (k>1) are built by viddet_amd.temporal (not wired yet)")
-    if block_conv_type != '2':
-        raise AssertionError("k must be greater than 1 to use 3D or 2+1D convolutions")   # yolo3.py:979
+    """wrappers.py:9-110 -> YOLOV3T (yolo3.py:959-1054).  norm_layer='syncbn' (the reference passes
+    SyncBatchNorm) selects the SyncBN collective.  k>1 builds the temporal-window variants."""
+    k = 1 if k is None else int(k)
+    # yolo3.py:978-985
+    if block_conv_type in ('3', '21'):
+        assert k > 1, "k must be greater than 1 to use 3D or 2+1D convolutions"
+        assert k_join_pos == 'late', "only 'late' pooling can be used when using 3D or 2+1D convolutions"
+        assert k_join_type is not None, "please specify a k_join_type: max, mean, or cat"
+    assert block_conv_type in ('2', '3', '21')
+    assert k_join_type in [None, 'max', 'mean', 'cat']
+    assert k_join_pos in [None, 'early', 'late']
+    if k > 1:
+        if k_join_type == 'cat':
+            raise NotImplementedError("k_join_type='cat' (channel stacking of the K frames) is not built yet")
+        if k_join_type is None or k_join_pos is None:
+            raise NotImplementedError("k>1 needs k_join_type (max|mean) and k_join_pos (early|late)")
     scope = None
     if norm_layer == 'syncbn':
         scope = (norm_kwargs or {}).get('scope', 'all')
-    net = YOLOV3(classes, syncbn_scope=scope, **kwargs)
+    net = YOLOV3(classes, syncbn_scope=scope, k=k, k_join_type=k_join_type, k_join_pos=k_join_pos,
+                 block_conv_type=block_conv_type, **kwargs)
     if freeze_base:
         for name, p in net.collect_params('stages.*').items():
             p.grad_req = 'null'

@@ -75,8 +75,9 @@ def _set_taps(d, taps):
 # --------------------------------------------------------------------------------------------
 def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo,
                out_stride=1, out_oy=0, out_ox=0, scale=None, shift=None, residual=None, ldr=0,
-               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1):
+               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0):
     d = ConvDesc()
+    d.tile = tile
     d.in_, d.wp, d.out = ptr(x), ptr(wp), ptr(out)
     d.scale, d.shift, d.residual = ptr(scale), ptr(shift), ptr(residual)
     d.N, d.Hi, d.Wi, d.Ci = N, Hi, Wi, Ci
@@ -99,7 +100,7 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
 
 
 def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
-             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1):
+             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0):
     """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo]."""
     N, Hi, Wi, Ci = x.shape
     Ho = (Hi + 2 * pad - k) // stride + 1
@@ -107,7 +108,7 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     ldo = Co if ldo is None else ldo
     conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
                taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
-               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr)
+               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile)
     return Ho, Wo
 
 
