@@ -179,13 +179,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     gload();
     lstore(0);
     __syncthreads();
+    // timing probes (VD_IGEMM_PROBE, results are garbage): bit0 skip the global loads, bit1 skip the LDS stores,
+    // bit2 skip the per-step barrier
+    const int probe = (p.flags >> 8) & 7;
     for (int ks = 0; ks < nks; ++ks) {
         const int cur = ks & 1;
         const bool more = (ks + 1 < nks);
-        if (more) gload();
+        if (more && !(probe & 1)) gload();
         compute(cur);
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
+        if (more && !(probe & 2)) lstore(cur ^ 1);
+        if (!(probe & 4)) __syncthreads();
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -290,13 +293,17 @@ int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
 constexpr int WG_BN = 128, WG_BP = 32;
 
 template <int WM, int WN, int TM, int TN, bool XF>
-__global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
-                                                    int splits, int64_t pix_per_split, const int64_t zd_in,
-                                                    const int64_t zd_do) {
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
+                                                             int splits, int64_t pix_per_split, const int64_t zd_in,
+                                                             const int64_t zd_do) {
     constexpr int BM = WM * TM * 32;
-    static_assert(WN * TN * 32 == WG_BN && WM * WN == 4, "tile");
-    constexpr int AROWS = 1024 / BM;          // pixel rows of the dout tile one pass of 256 float4 lanes covers
+    constexpr int NT = WM * WN * 64;          // 4 or 8 waves
+    static_assert(WN * TN * 32 == WG_BN && (WM * WN == 4 || WM * WN == 8), "tile");
+    constexpr int AROWS = NT * 4 / BM;        // pixel rows of the dout tile one pass of NT float4 lanes covers
     constexpr int APASS = WG_BP / AROWS;
+    constexpr int BROWS = NT * 4 / WG_BN;
+    constexpr int BPASS = WG_BP / BROWS;
+    static_assert(APASS >= 1 && BPASS >= 1, "loader");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][WG_BP][BM]      dout
     float* Bs = smem + 2 * WG_BP * BM;        // [2][WG_BP][WG_BN]   in
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
     if (p_end > P) p_end = P;
 
     // B operand: this thread's column chunk -> (tap, channel), fixed for the whole reduction
-    const int blpix = tid >> 5;               // 0..7 : pixel row inside a pass
-    const int blc = (tid & 31) * 4;
+    const int blpix = tid / (WG_BN / 4);
+    const int blc = (tid % (WG_BN / 4)) * 4;
     const int j = tile_j * WG_BN + blc;
     const bool j_ok = j < Ktot;
     const int tap = j_ok ? j / p.Ci : 0;
@@ -335,6 +342,22 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
         sh = *reinterpret_cast<const f32x4*>(p.in_shift + ci);
     }
 
+    // pixel cursor of each B pass: decoded once with divisions, then advanced by WG_BP pixels per K-step with
+    // carries (the per-step divisions were ~40 % of the loop's VALU work)
+    int cgx[BPASS], cgy[BPASS], cn[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int64_t pix = p_begin + blpix + BROWS * i;
+        const unsigned pu = (unsigned)(pix < P ? pix : 0);
+        const unsigned t = pu / (unsigned)p.Wg;
+        cgx[i] = (int)(pu - t * (unsigned)p.Wg);
+        const unsigned n_ = t / (unsigned)p.Hg;
+        cgy[i] = (int)(t - n_ * (unsigned)p.Hg);
+        cn[i] = (int)n_;
+    }
+    const int step_x = WG_BP % p.Wg, step_y = WG_BP / p.Wg;
+    const bool one_wrap = (step_y + 1) <= p.Hg;     // at most one image boundary per step (true unless the map is tiny)
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    f32x4 ra[APASS], rb[4];
+    f32x4 ra[APASS], rb[BPASS];
     auto gload = [&](int64_t pbase) {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
@@ -353,19 +376,12 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
             ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t pix = pbase + blpix + 8 * i;
-            // branch-free gather (zero page for everything out of range), 32-bit pixel decode
-            const bool pin = pix < p_end;
-            const unsigned pu = pin ? (unsigned)pix : 0u;
-            const unsigned t = pu / (unsigned)p.Wg;
-            const int gx = (int)(pu - t * (unsigned)p.Wg);
-            const unsigned n_ = t / (unsigned)p.Hg;
-            const int gy = (int)(t - n_ * (unsigned)p.Hg);
-            const int n = (int)n_;
+        for (int i = 0; i < BPASS; ++i) {
+            const int64_t pix = pbase + blpix + BROWS * i;
+            const int gx = cgx[i], gy = cgy[i], n = cn[i];
             const int iy = gy * p.in_stride + dy, ix = gx * p.in_stride + dx;
             const int fz = (n % p.Kfr) + dz;
-            const bool bok = pin && j_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
+            const bool bok = pix < p_end && j_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi &&
                              (unsigned)fz < (unsigned)p.Kfr;
             const int64_t o = (int64_t)((n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride) * p.Ci + boff;
             const int64_t sel = bok ? o : zd_in;
@@ -379,6 +395,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
                 }
             }
             rb[i] = vb;
+            // advance the cursor by WG_BP pixels
+            int nx = gx + step_x, ny = gy + step_y;
+            if (nx >= p.Wg) { nx -= p.Wg; ++ny; }
+            int nn = n;
+            if (one_wrap) {
+                if (ny >= p.Hg) { ny -= p.Hg; ++nn; }
+            } else {
+                nn += ny / p.Hg;
+                ny = ny % p.Hg;
+            }
+            cgx[i] = nx; cgy[i] = ny; cn[i] = nn;
         }
     };
     auto lstore = [&](int buf) {
@@ -387,7 +414,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const vd_wgrad_desc p, float
 #pragma unroll
         for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + (alpix + AROWS * i) * BM + alc) = ra[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + 8 * i) * WG_BN + blc) = rb[i];
+        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + BROWS * i) * WG_BN + blc) = rb[i];
     };
     auto compute = [&](int buf) {
         const float* a = As + buf * WG_BP * BM + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
@@ -456,7 +483,17 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
     const int64_t P = (int64_t)d.N * d.Hg * d.Wg;
     const int64_t tiles = vd_cdiv(d.Co, wgrad_bm(d)) * vd_cdiv((int64_t)d.T * d.Ci, WG_BN);
-    int64_t s = vd_cdiv(1024, tiles);                 // aim at ~4 blocks per CU
+    // blocks = tiles * splits run 512 at a time (2 per CU).  Pick the split count whose last round is fullest,
+    // searching from one round up to three; fewer splits win ties (every split adds a slab to write and re-read:
+    // a 128x256 output split 512 ways moved 134 MB for an 11 GFLOP layer).
+    int64_t s = 1;
+    double best = -1.0;
+    const int64_t lo = (512 / tiles) > 1 ? (512 / tiles) : 1, hi = vd_cdiv(1536, tiles);
+    for (int64_t c = lo; c <= hi; ++c) {
+        const double x = (double)(tiles * c) / 512.0;
+        const double fill = x / (double)vd_cdiv(tiles * c, 512);
+        if (fill > best + 0.02) { best = fill; s = c; }
+    }
     const int64_t maxs = vd_cdiv(P, 8 * WG_BP);        // >= 8 k-steps per block
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -480,11 +517,11 @@ void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, h
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_do = zp - d.dout;
     if (d.in_scale)
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, d, dst,
-                           splits, pps, zd_in, zd_do);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
+                           d, dst, splits, pps, zd_in, zd_do);
     else
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, d, dst,
-                           splits, pps, zd_in, zd_do);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
+                           d, dst, splits, pps, zd_in, zd_do);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,7 +629,12 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
     hipStream_t s = (hipStream_t)stream;
-    if (d->in_scale) dispatch_igemm<true>(*d, s);
+    static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
+    if (probe) {
+        vd_conv_desc dd = *d;
+        dd.flags |= (probe & 7) << 8;
+        dispatch_igemm<false>(dd, s);
+    } else if (d->in_scale) dispatch_igemm<true>(*d, s);
     else dispatch_igemm<false>(*d, s);
     VD_CHECK_LAUNCH("vd_conv_igemm");
     return VD_OK;
@@ -626,7 +668,12 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     const int bm = wgrad_bm(*d);
     if (bm == 32) launch_wgrad<1, 4, 1, 1>(*d, dst, splits, pps, s);
     else if (bm == 64) launch_wgrad<2, 2, 1, 2>(*d, dst, splits, pps, s);
-    else launch_wgrad<2, 2, 2, 2>(*d, dst, splits, pps, s);
+    else {
+        static const int wv = getenv("VD_WGRAD_VARIANT") ? atoi(getenv("VD_WGRAD_VARIANT")) : 2;
+        if (wv == 0) launch_wgrad<2, 2, 2, 2>(*d, dst, splits, pps, s);        // 128x128, 4 waves of 64x64
+        else if (wv == 1) launch_wgrad<4, 2, 1, 2>(*d, dst, splits, pps, s);   // 128x128, 8 waves of 32x64
+        else launch_wgrad<2, 4, 2, 1>(*d, dst, splits, pps, s);                // 128x128, 8 waves of 64x32
+    }
     VD_CHECK_LAUNCH("vd_conv_wgrad");
     if (splits > 1) {
         const int64_t n4 = (int64_t)d->Co * d->T * d->Ci / 4;

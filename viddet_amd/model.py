@@ -502,9 +502,15 @@ class YOLOV3(object):
                 else:
                     fan = int(np.prod(p.shape[1:]))
                     v = torch.randn(p.shape, generator=g) * math.sqrt(2.0 / fan)
+                    if 'prediction' in name:
+                        v *= 0.05     # raw box logits O(1): exp(raw_wh)*anchor stays a sane pixel size
                 p.set_data(v)
             elif name.endswith('gamma') or name.endswith('running_var'):
-                p.set_data(torch.ones(p.shape))
+                v = torch.ones(p.shape)
+                if init == 'he' and name.endswith('gamma') and '.body.1.1.' in name and name.startswith('stages'):
+                    v *= 0.3      # residual-branch gain < 1: 23 residual adds would otherwise double the activation
+                                  # variance per block in eval mode (running var = 1) and saturate every logit
+                p.set_data(v)
             elif name.endswith('bias'):
                 v = torch.zeros(p.shape)
                 if obj_bias != 0.0:
