@@ -77,9 +77,15 @@ typedef struct {
     const float* in_shift;
     float   in_slope;
     int32_t tile;           /* 0 = library heuristic; 1..8 = explicit tile variant (host autotuner) */
+    /* fused BatchNorm statistics (training forward, flags must be 0): per-M-tile partial sums
+     * stats_part[tile_m][0..Co) = sum, [Co..2Co) = sum of squares; vd_conv_igemm_mtiles() rows;
+     * finish with vd_bn_sum_partials().  NULL = off. */
+    float*  stats_part;
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);
+/* number of M tiles (rows of stats_part) the launch described by d will use */
+int vd_conv_igemm_mtiles(const vd_conv_desc* d);
 
 /* Weight gradient (autograd.backward wrt nn.Conv2D weight, train_yolov3.py:631):
  *   dwp[co][t*Ci+ci] = sum_{n,gy,gx} dout[n,gy,gx,co] * in[n, gy*is+dy[t], gx*is+dx[t], ci]
@@ -132,6 +138,9 @@ int vd_unpack_wgrad(const float* dwp, float* dw_oihw, int Co, int Ci, int kd, in
 int64_t vd_bn_stats_ws_bytes(int64_t M, int C);
 int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes,
                 void* stream);
+/* fp64 reduction of a partial table part[nblk][2C] (vd_conv_igemm stats_part) into sums[2C] */
+int64_t vd_bn_sum_partials_ws_bytes(int nblk, int C);
+int vd_bn_sum_partials(const float* part, int nblk, int C, double* sums, void* ws, int64_t ws_bytes, void* stream);
 /* from (possibly all-reduced) sums and total count: mean, biased var -> scale/shift for the
  * apply, saved mean/invstd for backward, running-stat update run = mom*run + (1-mom)*batch */
 int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,

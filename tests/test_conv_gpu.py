@@ -215,3 +215,47 @@ def test_conv_fwd_every_tile_variant(tile, shape):
                  residual=nchw_to_dev_nhwc(res, co_pad), tile=tile)
     torch.cuda.synchronize()
     assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_conv_fused_bn_statistics(tile):
+    """Per-channel sum / sum-of-squares produced by the conv epilogue == statistics of the conv output."""
+    import ctypes as C
+    from viddet_amd import ops, lib as L
+    n, ci, h, w, co, k, s, p = 3, 64, 13, 11, 96, 3, 1, 1
+    rng, x, wt = _mk(n, ci, h, w, co, k, 60 + tile)
+    ref = R.conv2d(x, wt, s, p)
+    out = torch.empty(n, h, w, co, device="cuda")
+    xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+    d = L.ConvDesc()
+    d.in_, d.wp, d.out = xd.data_ptr(), wp.data_ptr(), out.data_ptr()
+    d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, h, w, ci, h, w, s
+    ops._set_taps(d, ops.fwd_taps(k, p))
+    d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo, d.ldr, d.tile = 1, h, w, co, 1, co, co, tile
+    mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
+    part = torch.full((mt, 2 * co), 9.0, device="cuda")
+    d.stats_part = part.data_ptr()
+    L.check(L.load().vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
+    sums = torch.empty(2 * co, dtype=torch.float64, device="cuda")
+    L.check(L.load().vd_bn_sum_partials(part.data_ptr(), mt, co, sums.data_ptr(), None, 0, L.stream_ptr()), "vd_bn_sum_partials")
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out), ref) < TOL
+    sv = sums.cpu().numpy()
+    assert maxdiff(sv[:co], ref.sum(axis=(0, 2, 3))) < 1e-3
+    assert maxdiff(sv[co:], (ref ** 2).sum(axis=(0, 2, 3))) < 1e-3 * max(1.0, float((ref ** 2).sum(axis=(0, 2, 3)).max()) / 100)
+
+
+def test_bn_sum_partials_tall_table():
+    """Two-level path (more than 2048 partial rows) of the fused-statistics reduction."""
+    from viddet_amd import lib as L
+    rng = np.random.default_rng(70)
+    nblk, c = 5000, 48
+    part = rng.standard_normal((nblk, 2 * c)).astype(np.float32)
+    pd = dev(part)
+    sums = torch.empty(2 * c, dtype=torch.float64, device="cuda")
+    need = L.load().vd_bn_sum_partials_ws_bytes(nblk, c)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    L.check(L.load().vd_bn_sum_partials(pd.data_ptr(), nblk, c, sums.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "sum")
+    torch.cuda.synchronize()
+    assert maxdiff(sums.cpu().numpy(), part.astype(np.float64).sum(axis=0)) < 1e-9

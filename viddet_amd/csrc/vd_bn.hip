@@ -97,6 +97,39 @@ __global__ __launch_bounds__(1024) void k_bn_sum_partials(const float* __restric
     }
 }
 
+constexpr int SUMP_DIRECT = 2048, SUMP_CHUNKS = 64;
+
+// level 1 of the tall-table reduction: block (cb, r) sums rows [r*chunk, (r+1)*chunk) of 64 columns
+__global__ __launch_bounds__(1024) void k_bn_sum_partials_l1(const float* __restrict__ part, int nblk, int C2,
+                                                             double* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cx;
+    const int chunk = (nblk + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * chunk;
+    int r1 = r0 + chunk;
+    if (r1 > nblk) r1 = nblk;
+    double s = 0.0;
+    if (i < C2)
+        for (int b = r0 + sl; b < r1; b += 16) s += (double)part[(int64_t)b * C2 + i];
+    sh[sl][cx] = s;
+    __syncthreads();
+    if (sl == 0 && i < C2) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sh[j][cx];
+        out[(int64_t)blockIdx.y * C2 + i] = t;
+    }
+}
+
+__global__ void k_bn_sum_partials_l2(const double* __restrict__ in, int rows, int C2, double* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C2) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += in[(int64_t)r * C2 + i];
+    sums[i] = s;
+}
+
 __global__ void k_bn_finalize(const double* __restrict__ sums, double count, int C,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                               float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -223,6 +256,32 @@ int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_
     hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb,
                        2 * C, sums);
     VD_CHECK_LAUNCH("vd_bn_stats/sum");
+    return VD_OK;
+}
+
+int64_t vd_bn_sum_partials_ws_bytes(int nblk, int C) {
+    return nblk > SUMP_DIRECT ? (int64_t)SUMP_CHUNKS * 2 * C * (int64_t)sizeof(double) : 0;
+}
+
+int vd_bn_sum_partials(const float* part, int nblk, int C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(part && sums && nblk > 0 && C > 0, "vd_bn_sum_partials: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (nblk <= SUMP_DIRECT) {
+        hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, part, nblk, 2 * C, sums);
+        VD_CHECK_LAUNCH("vd_bn_sum_partials");
+        return VD_OK;
+    }
+    // tall tables (the fused conv statistics of the 416x416 layers have ~10^5 rows): two fixed-order levels
+    if (!ws || ws_bytes < vd_bn_sum_partials_ws_bytes(nblk, C)) {
+        vd_set_error("vd_bn_sum_partials: workspace too small");
+        return VD_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(k_bn_sum_partials_l1, dim3((unsigned)vd_cdiv(2 * C, 64), SUMP_CHUNKS), dim3(1024), 0, s, part, nblk, 2 * C,
+                       (double*)ws);
+    VD_CHECK_LAUNCH("vd_bn_sum_partials/l1");
+    hipLaunchKernelGGL(k_bn_sum_partials_l2, dim3((unsigned)vd_cdiv(2 * C, 256)), dim3(256), 0, s, (const double*)ws, SUMP_CHUNKS,
+                       2 * C, sums);
+    VD_CHECK_LAUNCH("vd_bn_sum_partials/l2");
     return VD_OK;
 }
 

@@ -227,6 +227,51 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
             }
         }
     }
+
+    // ---- fused BatchNorm statistics (training forward): per-column sum / sum of squares of this block's raw
+    // conv outputs, written as one row of the partial table [tile_m][2*Co] (no atomics: each (tile_m, column) has
+    // exactly one writer; vd_bn_sum_partials finishes the reduction in fp64 in a fixed order).  The C/D layout
+    // puts a column on a lane, so the sums are lane-local over the 16*TM rows, then folded across the two
+    // half-waves and the WM waves that share the column.
+    if (p.stats_part) {
+        float* red = smem;      // [WM][BN][2] : the operand tiles are dead after the last barrier of the K loop
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) +
+                                      4 * (lane >> 5);
+                    const float v = (m < M) ? acc[mi][ni][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 32) {
+                const int c = wn * TN * 32 + ni * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            const int col = tile_n * BN + c;
+            if (col < p.Co) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    s1 += red[(w * BN + c) * 2 + 0];
+                    s2 += red[(w * BN + c) * 2 + 1];
+                }
+                float* dstp = p.stats_part + (int64_t)tile_m * 2 * p.Co;
+                dstp[col] = s1;
+                dstp[p.Co + col] = s2;
+            }
+        }
+    }
 }
 
 const float* zero_page() {
@@ -260,14 +305,21 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
 // Tile variants (vd_conv_desc.tile; 0 = heuristic).  The host autotunes per launch record at plan-build
 // time (viddet_amd/ops.py autotune_conv): round quantisation (n blocks over 512 slots), how fast a lone
 // block runs and the K depth interact, and no closed-form rule picked the winner for every layer.
-template <bool XF>
-int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
+int igemm_resolve_tile(const vd_conv_desc& d) {
     int tile = d.tile;
     if (tile <= 0 || tile > 8) {
         if (d.Co <= 32) tile = 7;
         else if (d.Co <= 64) tile = 6;
         else tile = 2;
     }
+    return tile;
+}
+
+int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
+
+template <bool XF>
+int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
+    const int tile = igemm_resolve_tile(d);
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, XF>(d, s);   // 128 x 128, 4 waves of 64x64
         case 2: return launch_igemm<4, 2, 1, 2, XF>(d, s);   // 128 x 128, 8 waves of 32x64
@@ -628,6 +680,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
                "vd_conv_igemm: output grid exceeds output tensor");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
+    VD_REQUIRE(!d->stats_part || (d->flags & 7) == 0, "vd_conv_igemm: fused BN statistics need a raw (epilogue-free) output");
     hipStream_t s = (hipStream_t)stream;
     static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
     if (probe) {
@@ -638,6 +691,12 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     else dispatch_igemm<false>(*d, s);
     VD_CHECK_LAUNCH("vd_conv_igemm");
     return VD_OK;
+}
+
+int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
+    if (!d) return 0;
+    const int64_t M = (int64_t)d->N * d->Hg * d->Wg;
+    return (int)vd_cdiv(M, igemm_tile_bm(igemm_resolve_tile(*d)));
 }
 
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d) {

@@ -26,6 +26,7 @@ class ConvDesc(C.Structure):
         ("out_stride", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
         ("ldo", C.c_int32), ("ldr", C.c_int32), ("flags", C.c_int32), ("slope", C.c_float),
         ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float), ("tile", C.c_int32),
+        ("stats_part", _fp),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_version": (_i, []),
     "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
+    "vd_conv_igemm_mtiles": (_i, [C.POINTER(ConvDesc)]),
     "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad": (_i, [C.POINTER(WgradDesc), _p, _i64, _p]),
     "vd_stem_im2col": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     "vd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vd_bn_stats_ws_bytes": (_i64, [_i64, _i]),
     "vd_bn_stats": (_i, [_p, _i64, _i, _p, _p, _i64, _p]),
+    "vd_bn_sum_partials_ws_bytes": (_i64, [_i, _i]),
+    "vd_bn_sum_partials": (_i, [_p, _i, _i, _p, _p, _i64, _p]),
     "vd_bn_finalize": (_i, [_p, _d, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "vd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "vd_bn_apply_leaky": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),

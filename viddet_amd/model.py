@@ -103,45 +103,48 @@ class Program:
 _TUNE_CACHE = {}
 
 
-def autotune_program(prog, reps=3):
-    """Pick the fastest k_conv_igemm tile variant for every conv launch of a program (timed in place on the
-    program's own buffers with events on the launch stream; results cached per problem signature).
-    Disabled with VD_AUTOTUNE=0.  Tuning launches only rewrite buffers every real run rewrites first."""
+def autotune_desc(d, reps=3):
+    """Pick the fastest k_conv_igemm tile variant for one launch descriptor (timed in place on its own buffers
+    with events on the launch stream; cached per problem signature).  Disabled with VD_AUTOTUNE=0.
+    Tuning launches only rewrite buffers every real run rewrites first."""
     import os
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
         return
     lib = L.load()
     s = L.stream_ptr()
+    key = (d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, d.flags, bool(d.in_scale),
+           bool(d.stats_part))
+    if key in _TUNE_CACHE:
+        d.tile = _TUNE_CACHE[key]
+        return
+    if d.Co <= 32:
+        cands = [7]
+    elif d.Co <= 64:
+        cands = [6, 8]
+    else:
+        cands = [1, 2, 3, 4, 5]
+    best, best_t = cands[0], None
+    if len(cands) > 1:
+        for c in cands:
+            d.tile = c
+            L.check(lib.vd_conv_igemm(C.byref(d), s), 'vd_conv_igemm/tune')
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                lib.vd_conv_igemm(C.byref(d), s)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t:
+                best, best_t = c, t
+    d.tile = best
+    _TUNE_CACHE[key] = best
+
+
+def autotune_program(prog, reps=3):
     for (fname, fn, args) in prog.recs:
-        if fname != 'vd_conv_igemm':
-            continue
-        d = args[0]._obj
-        key = (d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, d.flags, bool(d.in_scale))
-        if key in _TUNE_CACHE:
-            d.tile = _TUNE_CACHE[key]
-            continue
-        if d.Co <= 32:
-            cands = [7]
-        elif d.Co <= 64:
-            cands = [6, 8]
-        else:
-            cands = [1, 2, 3, 4, 5]
-        best, best_t = cands[0], None
-        if len(cands) > 1:
-            for c in cands:
-                d.tile = c
-                L.check(lib.vd_conv_igemm(C.byref(d), s), 'vd_conv_igemm/tune')
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    lib.vd_conv_igemm(C.byref(d), s)
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if best_t is None or t < best_t:
-                    best, best_t = c, t
-        d.tile = best
-        _TUNE_CACHE[key] = best
+        if fname == 'vd_conv_igemm':
+            autotune_desc(args[0]._obj, reps)
 
 
 class Parameter:
@@ -388,6 +391,7 @@ class YOLOV3(object):
         self.use_graphs = False
         import os as _os
         self.overlap_wgrad = _os.environ.get('VD_OVERLAP', '1') != '0'   # wgrad GEMMs on a side stream (_build_train)
+        self.fuse_bn_stats = _os.environ.get('VD_FUSE_STATS', '1') != '0'  # BN statistics in the conv epilogue
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
@@ -738,6 +742,12 @@ class YOLOV3(object):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.process_group)
 
+        # partial-sum table of the fused BN statistics: rows = M tiles (>= 64 rows each), 2*Cout floats per row
+        smax = 16
+        for n in self.conv_nodes:
+            if n.bn:
+                smax = max(smax, ((B * n.fr * (H // n.div_out) * (W // n.div_out) + 63) // 64) * 2 * n.cout)
+        stats_ws = torch.empty(smax, device=dev)
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
         seg.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
@@ -768,8 +778,17 @@ class YOLOV3(object):
             z = bufs['z:' + n.dst]
             d = self._conv_desc(n, bufs, B, H, W, z)
             seg.hold(d)
-            seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
-            seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+            if self.fuse_bn_stats:
+                # BN statistics ride in the conv epilogue: one row of partial sums per M tile, reduced in fp64
+                d.stats_part = stats_ws.data_ptr()
+                autotune_desc(d)                                   # fixes the tile, hence the number of M tiles
+                mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
+                assert mt * 2 * n.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
+                seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
+                seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), mt, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+            else:
+                seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
+                seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
             count = float(M)
             if self._syncbn(n):
                 sums = n.sums
@@ -941,7 +960,7 @@ class YOLOV3(object):
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr))
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
-        seg.hold(ws_w, side)
+        seg.hold(ws_w, side, stats_ws)
         bwd.append(seg)
         for sg in fwd + bwd:
             if isinstance(sg, Program):
