@@ -149,7 +149,7 @@ def main():
 
     # ---- phase split (one extra step with device syncs between phases; not part of the timed region)
     phases = None
-    if rank == 0 and train:
+    if train:      # every rank runs it (allreduce_grads is a collective); rank 0 reports
         def timed(fn):
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -164,7 +164,7 @@ def main():
     # events on the launch stream over one more step
     roof = None
     extra = {}
-    if rank == 0:
+    if True:       # every rank replays (keeps ranks in lock-step if SyncBN collectives are in the programs)
         recs = []
         if train:
             net(x, gt, *tgd)
@@ -198,6 +198,16 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": None, "launches": ig[2], "avg_launch_ms": round(ig[1] / ig[2], 4),
                 "algorithmic_gflop_per_launch": round(ig[0] / ig[2] / 1e9, 3)}
+        roof["algorithmic_mb_per_launch"] = round(sum(m["bytes"] for f_, m, _, _ in recs if f_ == "vd_conv_igemm") / ig[2] / 1e6, 1)
+        # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this very
+        # command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
+        try:
+            if train and B == 64 and S == 416 and C == 80:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_train_b64_416_pmc_traffic.json")))
+                roof["traffic"] = round(pm["k_conv_igemm"]["hbm_mb_corrected"], 1)
+                roof["traffic_unit"] = "MB of HBM traffic per launch (PMC)"
+        except Exception:
+            pass
         for k, v in agg.items():
             if k != "vd_conv_igemm" and v[1] > 0:
                 extra[k] = {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}

@@ -955,9 +955,11 @@ class YOLOV3(object):
                 if acc:
                     d.residual = dsrc.data_ptr()
                 seg.hold(d, wpk)
+                nplans = n.stride * n.stride
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
-                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr))
+                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
+                    bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans))
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
         seg.hold(ws_w, side, stats_ws)
@@ -970,8 +972,12 @@ class YOLOV3(object):
     @staticmethod
     def _flops(n, B, H, W, kind):
         """Algorithmic FLOPs of one conv launch: 2*Cin*Cout*k*k*Ho*Wo per image."""
+        px_in = B * n.fr * (H // n.div_in) * (W // n.div_in)
+        px_out = B * n.fr * (H // n.div_out) * (W // n.div_out)
         return dict(kind=kind, node=n.name, k=n.k, stride=n.stride,
-                    flops=2.0 * n.cin * n.cout * n.kd * n.k * n.k * (H // n.div_out) * (W // n.div_out) * B * n.fr)
+                    flops=2.0 * n.cin * n.cout * n.kd * n.k * n.k * px_out,
+                    # algorithmic bytes: every operand tensor once (input, output/gradient, weights), fp32
+                    bytes=4.0 * (px_in * n.cin + px_out * n.cout + n.cout * n.cin * n.kd * n.k * n.k))
 
     def _ones(self, c):
         if not hasattr(self, '_const'):
