@@ -87,6 +87,17 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream);
 /* number of M tiles (rows of stats_part) the launch described by d will use */
 int vd_conv_igemm_mtiles(const vd_conv_desc* d);
 
+/* bf16 variant of vd_conv_igemm for inference (BASELINE configs[1] asks for bf16; the reference is fp32-only):
+ * in / wp / residual are bf16 (NHWC with Ci % 64 == 0, weights [Co][T*Ci]), accumulation and epilogue fp32,
+ * out is bf16 (out_f32 = 0) or fp32 (out_f32 = 1: prediction heads, shared decode / NMS kernels).
+ * Forward geometry only (out_stride 1).  d->tile: 0 = default, 1..5 = tile variant. */
+int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
+/* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */
+int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T,
+                        void* stream);
+/* stem im2col into 64 bf16 columns per pixel (27 real), from [N,H,W,3] (nchw=0) or [N,3,H,W] (nchw=1) fp32 */
+int vd_stem_im2col_bf16(const float* in, void* col, int N, int H, int W, int nchw, void* stream);
+
 /* Weight gradient (autograd.backward wrt nn.Conv2D weight, train_yolov3.py:631):
  *   dwp[co][t*Ci+ci] = sum_{n,gy,gx} dout[n,gy,gx,co] * in[n, gy*is+dy[t], gx*is+dx[t], ci]
  * split over `splits` pixel ranges into workspace slabs, then reduced deterministically.

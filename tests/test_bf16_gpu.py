@@ -1,0 +1,99 @@
+"""GPU: bf16 inference path (bf16 storage + v_mfma_f32_32x32x16_bf16, fp32 accumulate/epilogue, fp32 heads).
+The reference has no reduced precision, so the bound is defined here against the fp32 oracle:
+  * a single conv on bf16-representable inputs is exact to fp32 accumulation error (products of bf16 are exact in fp32);
+  * whole-network raw head outputs stay within 3 % of the head's max magnitude (bf16 has 8 significant bits and the
+    75-layer stack re-rounds every activation), and the detections keep their class and overlap the oracle's boxes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import net as ON
+from oracle import ops as R
+from tests.util import dev, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(2, 64, 13, 11, 128, 3, 1, 1), (3, 128, 8, 8, 192, 1, 1, 0), (2, 64, 17, 15, 64, 3, 2, 1)])
+def test_conv_bf16_single_layer(tile, shape):
+    from viddet_amd import ops, lib as L
+    n, ci, h, w, co, k, s, p = shape
+    rng = np.random.default_rng(90 + tile)
+    x = _bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = _bf16_round(rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k))
+    scale, shift = rng.uniform(0.5, 1.5, co), rng.standard_normal(co)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    res = _bf16_round(rng.standard_normal((n, co, ho, wo)))
+    z = R.conv2d(x, wt, s, p) * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    ref = R.leaky(z) + res
+    xd = torch.from_numpy(np.moveaxis(x, 1, -1).copy()).to(torch.bfloat16).cuda()
+    rd = torch.from_numpy(np.moveaxis(res, 1, -1).copy()).to(torch.bfloat16).cuda()
+    wp32 = torch.empty(co, k * k * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp32, co)
+    wb = torch.empty(co, k * k * ci, dtype=torch.bfloat16, device="cuda")
+    L.check(L.load().vd_pack_weight_bf16(wp32.data_ptr(), wb.data_ptr(), co, co, ci, ci, k * k, L.stream_ptr()), "pack")
+    for out_f32 in (0, 1):
+        out = torch.empty(n, ho, wo, co, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+        d = L.ConvDesc()
+        d.in_, d.wp, d.out = xd.data_ptr(), wb.data_ptr(), out.data_ptr()
+        d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, h, w, ci, ho, wo, s
+        ops._set_taps(d, ops.fwd_taps(k, p))
+        d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo, d.ldr, d.tile = 1, ho, wo, co, 1, co, co, tile
+        sc, sh = dev(scale), dev(shift)
+        d.scale, d.shift, d.residual = sc.data_ptr(), sh.data_ptr(), rd.data_ptr()
+        d.flags, d.slope = 1 | 2 | 4, 0.1
+        L.check(L.load().vd_conv_igemm_bf16(C.byref(d), out_f32, L.stream_ptr()), "vd_conv_igemm_bf16")
+        torch.cuda.synchronize()
+        got = np.moveaxis(out.float().cpu().numpy(), -1, 1)
+        tol = 2e-4 if out_f32 else 2e-4 + np.abs(ref).max() * 2 ** -8      # + one bf16 rounding of the output
+        assert maxdiff(got, ref) < tol
+
+
+def test_bf16_network_inference_close_to_fp32_oracle():
+    from viddet_amd.model import yolo3_darknet53
+    c, b, size = 4, 2, 96
+    P = ON.init_params(c, seed=51, obj_bias=-1.0)
+    net = yolo3_darknet53(["c%d" % i for i in range(c)])
+    for k, p in net.collect_params().items():
+        p.set_data(torch.from_numpy(P[k].astype(np.float32)))
+    rng = np.random.default_rng(51)
+    x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+    ids_r, sc_r, bx_r, rows_r, heads_r = ON.Net(P, c).detect(x.astype(np.float64))
+    ids32, sc32, bx32 = [t.clone() for t in net(dev(x))]
+    net.set_precision('bf16')
+    ids, sc, bx = net(dev(x))
+    torch.cuda.synchronize()
+    bufs = net._programs[('infer_bf16', b, size, size)][1]
+    for s_, hname in enumerate(net.head_names):
+        got = bufs[hname].cpu().numpy()[..., :3 * (5 + c)]
+        ref = np.moveaxis(heads_r[s_], 1, -1)
+        rel = maxdiff(got, ref) / np.abs(ref).max()
+        print("head", s_, "max err / max|head| =", rel)
+        assert rel < 3e-2
+    # detections: the top-scoring fp32 detections are found again (same class, IoU > 0.9)
+    ir, br, sr = ids_r[..., 0], bx_r, sc_r[..., 0]
+    ib, bb = ids.cpu().numpy()[..., 0], bx.cpu().numpy()
+    for bi in range(b):
+        top = [j for j in range(100) if ir[bi, j] >= 0 and sr[bi, j] > 0.3][:10]
+        for j in top:
+            cand = np.nonzero(ib[bi] == ir[bi, j])[0]
+            assert len(cand) > 0
+            a = br[bi, j]
+            best = 0.0
+            for q in cand:
+                bq = bb[bi, q]
+                iw = max(0.0, min(a[2], bq[2]) - max(a[0], bq[0])); ih = max(0.0, min(a[3], bq[3]) - max(a[1], bq[1]))
+                u = (a[2] - a[0]) * (a[3] - a[1]) + (bq[2] - bq[0]) * (bq[3] - bq[1]) - iw * ih
+                best = max(best, iw * ih / u if u > 0 else 0.0)
+            assert best > 0.9, (bi, j, best)
+    net.set_precision('fp32')
+    again = net(dev(x))
+    torch.cuda.synchronize()
+    assert torch.equal(again[0], ids32) and torch.equal(again[2], bx32)

@@ -1,0 +1,302 @@
+// vd_conv_bf16.hip — bf16 storage / bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate) variant of the
+// tap-list implicit-GEMM convolution, for the inference configs of BASELINE.json that ask for bf16
+// (configs[1]; the reference itself is fp32-only, so this path is judged against the fp32 oracle with a
+// stated bf16 tolerance).
+//
+// Same GEMM view and the same 16-byte-chunk loader as vd_conv.hip: a K-step is one 128-byte run of one
+// tap per pixel = 64 bf16 channels, LDS rows are 128 B + 16 B pad (conflict-free ds_read_b128), and the
+// MFMA operand map is the bf16 one (guide §3): lane l holds A[row l&31][k = 8*(l>>5) .. +7] = exactly the
+// 16 bytes it reads at byte offset 32*kc + 16*(l>>5) of its row, so ONE ds_read_b128 feeds ONE MFMA of K=16.
+// Activations NHWC bf16 with the channel count padded to a multiple of 64; weights packed [Co_pad][T*Ci] bf16;
+// epilogue (BN-eval fold / bias, LeakyReLU, residual) in fp32, output bf16 (layers) or fp32 (prediction heads,
+// so the decode / NMS kernels are shared with the fp32 path).
+#include "vd_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int ROW_B = 144;              // LDS row: 128 B of K + 16 B pad
+constexpr int KCH = 64;                 // bf16 channels per K-step
+
+__device__ __attribute__((aligned(64))) float g_zero_page_b[64];
+
+struct RowInfoB {
+    int64_t off;     // element offset (bf16) of (pixel of tap (0,0,0), channel 8*(tid&7))
+    unsigned mask;
+};
+
+template <int WM, int WN, int TM, int TN, bool OUT_F32>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
+                                                                  const int64_t zd_w) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPP = NT / 8;
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile vs loader");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                       // [2][BM][ROW_B]
+    unsigned char* Bs = smem_b + 2 * BM * ROW_B;      // [2][BN][ROW_B]
+    const __bf16* in = reinterpret_cast<const __bf16*>(p.in);
+    const __bf16* wp = reinterpret_cast<const __bf16*>(p.wp);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
+    const int ntile = (p.Co + BN - 1) / BN;
+    const int lid = vd_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % ntile, tile_m = lid / ntile;
+    const int Ktot = p.T * p.Ci;
+    const int lrow = tid >> 3;
+    const int lc8 = (tid & 7) * 8;            // bf16 element offset of this lane's 16-byte chunk
+
+    RowInfoB ri[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
+        ri[i].off = 0;
+        ri[i].mask = 0u;
+        if (m < M) {
+            const unsigned mu = (unsigned)m;
+            const unsigned t = mu / (unsigned)p.Wg;
+            const int gx = (int)(mu - t * (unsigned)p.Wg);
+            const unsigned n_ = t / (unsigned)p.Hg;
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            const int n = (int)n_;
+            const int iy0 = gy * p.in_stride, ix0 = gx * p.in_stride;
+            const int fz0 = n % p.Kfr;
+            ri[i].off = (int64_t)((n * p.Hi + iy0) * p.Wi + ix0) * p.Ci + lc8;
+            unsigned mk = 0u;
+            for (int t2 = 0; t2 < p.T; ++t2) {
+                const bool ok = (unsigned)(iy0 + p.dy[t2]) < (unsigned)p.Hi && (unsigned)(ix0 + p.dx[t2]) < (unsigned)p.Wi &&
+                                (unsigned)(fz0 + p.dz[t2]) < (unsigned)p.Kfr;
+                mk |= ok ? (1u << t2) : 0u;
+            }
+            ri[i].mask = mk;
+        }
+    }
+    int64_t boff[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = tile_n * BN + lrow + RPP * i;
+        boff[i] = (n < p.Co) ? (int64_t)n * Ktot + lc8 : (int64_t)-1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    f32x4 ra[AP], rb[BP];
+    int t_tap = 0, c0 = 0;
+
+    auto gload = [&]() {
+        const int dy = p.dy[t_tap], dx = p.dx[t_tap], dz = p.dz[t_tap];
+        const int64_t soff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + c0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool ok = (ri[i].mask >> t_tap) & 1u;
+            const int64_t sel = ok ? ri[i].off + soff : zd_in;
+            ra[i] = *reinterpret_cast<const f32x4*>(in + sel);
+        }
+        const int64_t koff = (int64_t)t_tap * p.Ci + c0;
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
+            rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
+        }
+        c0 += KCH;
+        if (c0 >= p.Ci) { c0 = 0; ++t_tap; }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* a = As + buf * BM * ROW_B;
+        unsigned char* b = Bs + buf * BN * ROW_B;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(a + (lrow + RPP * i) * ROW_B + (tid & 7) * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(b + (lrow + RPP * i) * ROW_B + (tid & 7) * 16) = rb[i];
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* a = As + buf * BM * ROW_B + (wm * TM * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
+        const unsigned char* b = Bs + buf * BN * ROW_B + (wn * TN * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * ROW_B + kc * 32);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * ROW_B + kc * 32);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    const int nks = p.T * (p.Ci / KCH);
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = (ks + 1 < nks);
+        if (more) gload();
+        compute(cur);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs)
+    const __bf16* res = reinterpret_cast<const __bf16*>(p.residual);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + (lane & 31);
+        const bool cok = col < p.Co;
+        float sc = 1.f, sh = 0.f;
+        if ((p.flags & VD_EPI_AFFINE) && cok) {
+            if (p.scale) sc = p.scale[col];
+            if (p.shift) sh = p.shift[col];
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (!cok || m >= M) continue;
+                float v = acc[mi][ni][r];
+                if (p.flags & VD_EPI_AFFINE) v = v * sc + sh;
+                if (p.flags & VD_EPI_LEAKY) v = v > 0.f ? v : v * p.slope;
+                if (p.flags & VD_EPI_RESIDUAL) v += (float)res[m * p.ldr + col];
+                if (OUT_F32) p.out[m * p.ldo + col] = v;
+                else reinterpret_cast<__bf16*>(p.out)[m * p.ldo + col] = (__bf16)v;
+            }
+        }
+    }
+}
+
+const float* zero_page_b() {
+    static const float* zp = nullptr;
+    if (!zp) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_b)) != hipSuccess) q = nullptr;
+        zp = (const float*)q;
+    }
+    return zp;
+}
+
+template <int WM, int WN, int TM, int TN, bool OUT_F32>
+void launch_b(const vd_conv_desc& d, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int lds = 2 * (BM + BN) * ROW_B;
+    static bool attr_done = false;
+    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
+    const int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page_b());
+    const int64_t zd_in = zp - reinterpret_cast<const __bf16*>(d.in);
+    const int64_t zd_w = zp - reinterpret_cast<const __bf16*>(d.wp);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w);
+}
+
+template <bool OUT_F32>
+void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
+    int tile = d.tile;
+    if (tile <= 0 || tile > 5) tile = 2;
+    switch (tile) {
+        case 1: return launch_b<2, 2, 2, 2, OUT_F32>(d, s);   // 128 x 128, 4 waves of 64x64
+        case 2: return launch_b<4, 2, 1, 2, OUT_F32>(d, s);   // 128 x 128, 8 waves of 32x64
+        case 3: return launch_b<2, 4, 2, 1, OUT_F32>(d, s);   // 128 x 128, 8 waves of 64x32
+        case 4: return launch_b<2, 2, 1, 2, OUT_F32>(d, s);   //  64 x 128, 4 waves
+        default: return launch_b<2, 4, 1, 1, OUT_F32>(d, s);  //  64 x 128, 8 waves
+    }
+}
+
+__global__ void k_pack_bf16(const float* __restrict__ src, __bf16* __restrict__ dst, int Co, int Co_pad, int Ci,
+                            int Ci_pad, int T) {
+    // src fp32 fwd-packed [>=Co][T*Ci] -> dst bf16 [Co_pad][T*Ci_pad], zero padded rows / channels
+    const int64_t total = (int64_t)Co_pad * T * Ci_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ci_pad);
+        const int64_t r = i / Ci_pad;
+        const int t = (int)(r % T);
+        const int co = (int)(r / T);
+        const float v = (co < Co && ci < Ci) ? src[((int64_t)co * T + t) * Ci + ci] : 0.f;
+        dst[i] = (__bf16)v;
+    }
+}
+
+__global__ void k_stem_im2col_bf16(const float* __restrict__ in, __bf16* __restrict__ col, int N, int H, int W, int nchw) {
+    // col [N,H,W,64] bf16: entries (ky*3+kx)*3+c for k < 27, zero above
+    const int64_t total = (int64_t)N * H * W * 8;          // one 16-byte chunk (8 bf16) per thread
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 7);
+        const int64_t pix = i >> 3;
+        const int x = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = q * 8 + e;
+            float val = 0.f;
+            if (k < 27) {
+                const int c = k % 3, tap = k / 3;
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    val = nchw ? in[(((int64_t)n * 3 + c) * H + iy) * W + ix] : in[(((int64_t)n * H + iy) * W + ix) * 3 + c];
+            }
+            v[e] = (__bf16)val;
+        }
+        reinterpret_cast<bf16x8*>(col)[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
+    VD_REQUIRE(d && d->in && d->wp && d->out, "vd_conv_igemm_bf16: null pointer");
+    VD_REQUIRE(d->Ci > 0 && d->Ci % 64 == 0, "vd_conv_igemm_bf16: Ci=%d must be a positive multiple of 64", d->Ci);
+    VD_REQUIRE(d->T >= 1 && d->T <= VD_MAX_TAPS && d->Kfr >= 1 && d->N % d->Kfr == 0, "vd_conv_igemm_bf16: bad taps");
+    VD_REQUIRE(d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg,
+               "vd_conv_igemm_bf16: forward geometry only");
+    VD_REQUIRE(d->ldo >= d->Co && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31) && (int64_t)d->N * d->Hg * d->Wg < (1ll << 31),
+               "vd_conv_igemm_bf16: bad sizes");
+    VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
+    VD_REQUIRE(!d->in_scale && !d->stats_part, "vd_conv_igemm_bf16: in-load transform / fused statistics are fp32-path features");
+    if (out_f32) dispatch_b<true>(*d, (hipStream_t)stream);
+    else dispatch_b<false>(*d, (hipStream_t)stream);
+    VD_CHECK_LAUNCH("vd_conv_igemm_bf16");
+    return VD_OK;
+}
+
+int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T, void* stream) {
+    VD_REQUIRE(wp_f32 && wp_bf16 && Co > 0 && Co_pad >= Co && Ci > 0 && Ci_pad >= Ci && T > 0, "vd_pack_weight_bf16: bad args");
+    const int64_t total = (int64_t)Co_pad * T * Ci_pad;
+    const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_pack_bf16, dim3(nb), dim3(256), 0, (hipStream_t)stream, wp_f32, (__bf16*)wp_bf16, Co, Co_pad, Ci, Ci_pad, T);
+    VD_CHECK_LAUNCH("vd_pack_weight_bf16");
+    return VD_OK;
+}
+
+int vd_stem_im2col_bf16(const float* in, void* col, int N, int H, int W, int nchw, void* stream) {
+    VD_REQUIRE(in && col && N > 0 && H > 0 && W > 0, "vd_stem_im2col_bf16: bad args");
+    const int64_t total = (int64_t)N * H * W * 8;
+    const int nb = (int)(vd_cdiv(total, 256) < 8192 ? vd_cdiv(total, 256) : 8192);
+    hipLaunchKernelGGL(k_stem_im2col_bf16, dim3(nb), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)col, N, H, W, nchw);
+    VD_CHECK_LAUNCH("vd_stem_im2col_bf16");
+    return VD_OK;
+}
+
+}  // extern "C"

@@ -57,6 +57,9 @@ SIGNATURES = {
     "vd_version": (_i, []),
     "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
     "vd_conv_igemm_mtiles": (_i, [C.POINTER(ConvDesc)]),
+    "vd_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _i, _p]),
+    "vd_pack_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vd_stem_im2col_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad": (_i, [C.POINTER(WgradDesc), _p, _i64, _p]),
     "vd_stem_im2col": (_i, [_p, _p, _i, _i, _i, _i, _p]),

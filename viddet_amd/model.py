@@ -392,6 +392,7 @@ class YOLOV3(object):
         import os as _os
         self.overlap_wgrad = _os.environ.get('VD_OVERLAP', '1') != '0'   # wgrad GEMMs on a side stream (_build_train)
         self.fuse_bn_stats = _os.environ.get('VD_FUSE_STATS', '1') != '0'  # BN statistics in the conv epilogue
+        self.precision = 'fp32'        # inference precision: 'fp32' | 'bf16' (set_precision)
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
@@ -492,7 +493,7 @@ class YOLOV3(object):
     def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
         # yolo3.py:1208-1228
         self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
-        self._programs = {k: v for k, v in self._programs.items() if k[0] != 'infer'}
+        self._programs = {k: v for k, v in self._programs.items() if k[0] not in ('infer', 'infer_bf16')}
         self._graph_cache.clear()
 
     def initialize(self, init='uniform', seed=233, obj_bias=0.0):
@@ -572,6 +573,7 @@ class YOLOV3(object):
     def _params_changed(self):
         self._fold_dirty = True
         self._dgrad_dirty = True
+        self._bf16_fresh = False
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, key, B, H, W, train):
@@ -688,15 +690,149 @@ class YOLOV3(object):
                 ops.bn_fold_eval(n.gamma, n.beta, n.rmean, n.rvar, BN_EPS, n.fold_scale, n.fold_shift)
         self._fold_dirty = False
 
+    # ------------------------------------------------------------------ bf16 inference
+    def set_precision(self, precision):
+        """'fp32' (reference precision) or 'bf16' (BASELINE configs[1]): bf16 storage + bf16 MFMA with fp32
+        accumulation and fp32 epilogue for inference; the prediction heads stay fp32."""
+        assert precision in ('fp32', 'bf16')
+        if precision == 'bf16' and self._k > 1:
+            raise NotImplementedError("bf16 inference is built for k=1")
+        self.precision = precision
+
+    def _build_infer_bf16(self, B, H, W):
+        dev = self.device
+        lib = L.load()
+        cp = lambda c: round_up(c, 64)
+        bufs = {'in': torch.empty(B, 3, H, W, device=dev),
+                'col': torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=dev)}
+        for name, (c, div, ld, fr) in self.tensors.items():
+            if name == 'in':
+                continue
+            if name in self.head_names:
+                bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
+            else:
+                bufs[name] = torch.empty(B, H // div, W // div, cp(c), dtype=torch.bfloat16, device=dev)
+        prog = Program()
+        prog.add('vd_stem_im2col_bf16', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
+        packs = []
+        s = L.stream_ptr()
+        for n in self.nodes:
+            if isinstance(n, UpcatNode):
+                o = bufs[n.dst]
+                # 16-byte-unit copy kernel: pass channel counts as if fp32 (bf16 count / 2)
+                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
+                         o.shape[1], o.shape[2], cp(n.cu) // 2, cp(n.cr) // 2)
+                continue
+            ci_p = 64 if n.stem else cp(n.cin)
+            co_p = n.co_pad if n.head else cp(n.cout)
+            wb = torch.empty(co_p * n.T * ci_p, dtype=torch.bfloat16, device=dev)
+            packs.append((n, wb, co_p, ci_p))
+            d = ConvDesc()
+            x = bufs['col'] if n.stem else bufs[n.src]
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            d.in_, d.wp, d.out = x.data_ptr(), wb.data_ptr(), bufs[n.dst].data_ptr()
+            d.N, d.Hi, d.Wi, d.Ci = B, Hi, Wi, ci_p
+            d.Hg, d.Wg, d.in_stride = Ho, Wo, n.stride
+            ops._set_taps(d, n.taps())
+            d.Kfr = 1
+            d.Ho, d.Wo, d.Co = Ho, Wo, co_p
+            d.out_stride, d.out_oy, d.out_ox = 1, 0, 0
+            d.ldo = d.ldr = co_p
+            if n.head:
+                d.flags, d.shift = EPI_AFFINE, n.bias.data_ptr()
+            else:
+                sc = torch.zeros(co_p, device=dev)
+                sh = torch.zeros(co_p, device=dev)
+                n.bf_scale, n.bf_shift = sc, sh
+                d.flags = EPI_AFFINE | EPI_LEAKY | (EPI_RESIDUAL if n.residual else 0)
+                d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+                if n.residual:
+                    d.residual = bufs[n.residual].data_ptr()
+            d.slope = LEAKY_SLOPE
+            prog.hold(d, wb)
+            prog.add('vd_conv_igemm_bf16', C.byref(d), 1 if n.head else 0, meta=self._flops(n, B, H, W, 'fwd'))
+        grids = self._grid(H, W)
+        hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
+                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+        P = 3 * sum(g * g for g in grids)
+        cap = min(self.num_class * P, 1 << 18)
+        o = dict(cand_score=torch.empty(B, cap, device=dev), cand_row=torch.empty(B, cap, dtype=torch.int32, device=dev),
+                 counts=torch.zeros(B, dtype=torch.int32, device=dev), ids=torch.empty(B, self.post_nms, 1, device=dev),
+                 scores=torch.empty(B, self.post_nms, 1, device=dev), bboxes=torch.empty(B, self.post_nms, 4, device=dev),
+                 rows=torch.empty(B, self.post_nms, dtype=torch.int32, device=dev),
+                 overflow=torch.zeros(B, dtype=torch.int32, device=dev))
+        prog.hold(hd, o)
+        prog.add('vd_yolo_decode_filter', C.byref(hd), 0.01, o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
+                 o['counts'].data_ptr())
+        prog.add('vd_nms_topk', C.byref(hd), o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
+                 o['counts'].data_ptr(), float(self.nms_thresh), int(self.nms_topk), int(self.post_nms),
+                 o['ids'].data_ptr(), o['scores'].data_ptr(), o['bboxes'].data_ptr(), o['rows'].data_ptr(),
+                 o['overflow'].data_ptr(), 4 * B)
+        return prog, bufs, o, packs
+
+    def _refresh_bf16(self, packs):
+        """Re-derive the bf16 weight images and the padded fp32 scale/shift vectors after a parameter change."""
+        self._refresh_fold()
+        lib = L.load()
+        s = L.stream_ptr()
+        for n, wb, co_p, ci_p in packs:
+            L.check(lib.vd_pack_weight_bf16(n.wp.data_ptr(), wb.data_ptr(), n.co_pad, co_p, n.ci_eff, ci_p, n.T, s),
+                    'vd_pack_weight_bf16')
+            if n.bn:
+                n.bf_scale[:n.cout].copy_(n.fold_scale)
+                n.bf_shift[:n.cout].copy_(n.fold_shift)
+
+    def _tune_bf16(self, prog):
+        import os
+        if os.environ.get("VD_AUTOTUNE", "1") == "0":
+            return
+        lib = L.load()
+        s = L.stream_ptr()
+        for (fname, fn, args) in prog.recs:
+            if fname != 'vd_conv_igemm_bf16':
+                continue
+            d, of32 = args[0]._obj, args[1]
+            key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.flags, of32)
+            if key not in _TUNE_CACHE:
+                best, best_t = 2, None
+                for c in (1, 2, 3, 4, 5):
+                    d.tile = c
+                    L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if best_t is None or t < best_t:
+                        best, best_t = c, t
+                _TUNE_CACHE[key] = best
+            d.tile = _TUNE_CACHE[key]
+
     # ------------------------------------------------------------------ inference
     def _forward_infer(self, x):
         B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
         assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
-        key = ('infer', B, H, W)
-        if key not in self._programs:
-            self._programs[key] = self._build_infer(B, H, W)
-        prog, bufs, o = self._programs[key]
-        self._refresh_fold()
+        if self.precision == 'bf16':
+            key = ('infer_bf16', B, H, W)
+            if key not in self._programs:
+                built = self._build_infer_bf16(B, H, W)
+                self._refresh_bf16(built[3])
+                self._bf16_fresh = True
+                self._tune_bf16(built[0])
+                self._programs[key] = built
+            prog, bufs, o, packs = self._programs[key]
+            if self._fold_dirty or not getattr(self, '_bf16_fresh', False):
+                self._refresh_bf16(packs)
+                self._bf16_fresh = True
+        else:
+            key = ('infer', B, H, W)
+            if key not in self._programs:
+                self._programs[key] = self._build_infer(B, H, W)
+            prog, bufs, o = self._programs[key]
+            self._refresh_fold()
         bufs['in'].copy_(x.reshape(bufs['in'].shape))
         if self.use_graphs:
             g = self._graph_cache.get(key)
