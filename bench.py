@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = bf16 storage/MFMA inference (detect mode only)")
+    ap.add_argument("--graphs", action="store_true", help="replay the inference program as a captured HIP graph")
     ap.add_argument("--detail", default=None, help="write a per-launch conv table (JSON) to this path")
     ap.add_argument("--obj-bias", type=float, default=None,
                     help="objectness bias of the random-init heads (default: calibrated so ~2%% of score rows pass)")
@@ -129,6 +130,7 @@ def main():
             v.view(3, -1)[:, 4] = best[0]
             p.set_data(v)
         pass_info = {"obj_bias": best[0], "pass_fraction": round(best[1], 5)}
+        net.use_graphs = bool(a.graphs)
 
         def step():
             net(x)
@@ -243,7 +245,8 @@ def main():
                                     "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),
                        "classes": C, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "syncbn": a.syncbn, "score_filter": (None if train else pass_info)},
+                       "syncbn": a.syncbn, "score_filter": (None if train else pass_info),
+                       "hip_graph": bool(a.graphs) and not train},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra, "phases": phases,
         }
         if gflop:

@@ -142,13 +142,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     gload();
     lstore(0);
     __syncthreads();
+    const int probe = (p.flags >> 8) & 7;      // timing probes (VD_IGEMM_PROBE), see vd_conv.hip
     for (int ks = 0; ks < nks; ++ks) {
         const int cur = ks & 1;
         const bool more = (ks + 1 < nks);
-        if (more) gload();
+        if (more && !(probe & 1)) gload();
         compute(cur);
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
+        if (more && !(probe & 2)) lstore(cur ^ 1);
+        if (!(probe & 4)) __syncthreads();
     }
 
     // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs)
@@ -210,8 +211,10 @@ void launch_b(const vd_conv_desc& d, hipStream_t s) {
 template <bool OUT_F32>
 void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 5) tile = 2;
+    if (tile <= 0 || tile > 7) tile = 2;
     switch (tile) {
+        case 6: return launch_b<4, 2, 2, 2, OUT_F32>(d, s);   // 256 x 128, 8 waves of 64x64 (1 block / CU)
+        case 7: return launch_b<2, 4, 2, 2, OUT_F32>(d, s);   // 128 x 256, 8 waves of 64x64 (1 block / CU)
         case 1: return launch_b<2, 2, 2, 2, OUT_F32>(d, s);   // 128 x 128, 4 waves of 64x64
         case 2: return launch_b<4, 2, 1, 2, OUT_F32>(d, s);   // 128 x 128, 8 waves of 32x64
         case 3: return launch_b<2, 4, 2, 1, OUT_F32>(d, s);   // 128 x 128, 8 waves of 64x32
@@ -275,8 +278,11 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
                "vd_conv_igemm_bf16: bad sizes");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
     VD_REQUIRE(!d->in_scale && !d->stats_part, "vd_conv_igemm_bf16: in-load transform / fused statistics are fp32-path features");
-    if (out_f32) dispatch_b<true>(*d, (hipStream_t)stream);
-    else dispatch_b<false>(*d, (hipStream_t)stream);
+    static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
+    vd_conv_desc dd = *d;
+    dd.flags |= (probe & 7) << 8;
+    if (out_f32) dispatch_b<true>(dd, (hipStream_t)stream);
+    else dispatch_b<false>(dd, (hipStream_t)stream);
     VD_CHECK_LAUNCH("vd_conv_igemm_bf16");
     return VD_OK;
 }
