@@ -75,7 +75,8 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get("VD_FORCE_DIST", "0") == "1"      # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     from viddet_amd.model import yolo3_darknet53
     from viddet_amd.targets import synthetic_batch, prefetch_targets
@@ -137,7 +138,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -149,7 +150,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -231,7 +232,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.mode, S, C)
 
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.barrier()
     if rank == 0:
         gflop = 197.3 if (train and S == 416 and C == 80) else None
@@ -252,7 +253,7 @@ def main():
         if gflop:
             out["model_tflops"] = round(fps * gflop / 1e3, 2)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -108,9 +108,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     f32x4 ra[AP], rb[BP];
     int t_tap = 0, c0 = 0;   // k-step cursor of the NEXT tile to load
 
+    // tap part of the wave-uniform source offset: refreshed only when the tap changes (every Ci/32 K-steps), so the
+    // scalar loads of dy/dx/dz and their s_waitcnt leave the per-step critical path
+    auto tap_off = [&](int t) -> int64_t {
+        return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
+    };
+    int64_t tap_soff = tap_off(0);
     auto gload = [&]() {
-        const int dy = p.dy[t_tap], dx = p.dx[t_tap], dz = p.dz[t_tap];
-        const int64_t soff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + c0;     // wave-uniform
+        const int64_t soff = tap_soff + c0;     // wave-uniform
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (XF) {
             sc = *reinterpret_cast<const f32x4*>(p.in_scale + c0 + lc4);
@@ -140,7 +145,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
             rb[i] = *reinterpret_cast<const f32x4*>(p.wp + sel);
         }
         c0 += BK;
-        if (c0 >= p.Ci) { c0 = 0; ++t_tap; }
+        if (c0 >= p.Ci) {
+            c0 = 0;
+            ++t_tap;
+            if (t_tap < p.T) tap_soff = tap_off(t_tap);
+        }
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * BM * LDS_LD;

@@ -94,9 +94,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     f32x4 ra[AP], rb[BP];
     int t_tap = 0, c0 = 0;
 
+    auto tap_off = [&](int t) -> int64_t {
+        return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
+    };
+    int64_t tap_soff = tap_off(0);
     auto gload = [&]() {
-        const int dy = p.dy[t_tap], dx = p.dx[t_tap], dz = p.dz[t_tap];
-        const int64_t soff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + c0;
+        const int64_t soff = tap_soff + c0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const bool ok = (ri[i].mask >> t_tap) & 1u;
@@ -110,7 +113,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
         }
         c0 += KCH;
-        if (c0 >= p.Ci) { c0 = 0; ++t_tap; }
+        if (c0 >= p.Ci) {
+            c0 = 0;
+            ++t_tap;
+            if (t_tap < p.T) tap_soff = tap_off(t_tap);
+        }
     };
     auto lstore = [&](int buf) {
         unsigned char* a = As + buf * BM * ROW_B;

@@ -393,6 +393,10 @@ class YOLOV3(object):
         self.overlap_wgrad = _os.environ.get('VD_OVERLAP', '1') != '0'   # wgrad GEMMs on a side stream (_build_train)
         self.fuse_bn_stats = _os.environ.get('VD_FUSE_STATS', '1') != '0'  # BN statistics in the conv epilogue
         self.precision = 'fp32'        # inference precision: 'fp32' | 'bf16' (set_precision)
+        self.bucketed_allreduce = _os.environ.get('VD_BUCKETED', '1') != '0'
+        self.bucket_elems = 16 << 20   # 64 MB of fp32 gradients per all-reduce
+        self._pending_reduces = []
+        self._reduced_from = 1 << 62
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
@@ -973,6 +977,7 @@ class YOLOV3(object):
                 (side if on_side else torch.cuda.current_stream()).wait_event(e)
             return f
 
+        bucket_hi, bucket_acc = [self.n_weight], [0]
         written = set(self.head_names)     # gradients already produced (the loss kernel wrote d:head*)
         dgrad_packs = []                   # (node, plan, packed weight buffer) re-packed when weights change
 
@@ -1070,6 +1075,15 @@ class YOLOV3(object):
                 last_side[0] = e_done
             else:
                 seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
+            # bucketed gradient all-reduce, overlapped with the rest of the backward pass: weight gradients complete
+            # in reverse arena order on the stream that runs the wgrad GEMMs, so every time ~64 MB of the arena tail
+            # is final an async all-reduce of that contiguous range is queued behind them (RCCL syncs with that
+            # stream); allreduce_grads() later waits for the handles and reduces the small gamma/beta/bias range.
+            bucket_acc[0] += n.w_numel
+            if self.bucketed_allreduce and (bucket_acc[0] >= self.bucket_elems or n is self.conv_nodes[0]):
+                lo, hi = n.w_off, bucket_hi[0]
+                seg.add_py(self._bucket_launcher(lo, hi, side))
+                bucket_hi[0], bucket_acc[0] = lo, 0
             if n.stem:
                 continue
             # data gradient into d:src
@@ -1182,10 +1196,38 @@ class YOLOV3(object):
         return self._forward_train(x, *args)
 
     # ------------------------------------------------------------------ optimiser / DP hooks
+    def _dp_active(self):
+        import os
+        return torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            (torch.distributed.get_world_size(self.process_group) > 1 or os.environ.get("VD_FORCE_DIST") == "1")
+
+    def _bucket_launcher(self, lo, hi, side):
+        def f():
+            if not self._dp_active():
+                return
+            st = side if side is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                h = torch.distributed.all_reduce(self.grads[lo:hi], group=self.process_group, async_op=True)
+            self._pending_reduces.append(h)
+            self._reduced_from = min(self._reduced_from, lo)
+        return f
+
     def allreduce_grads(self):
-        """kvstore-'local' replacement (train_yolov3.py:530): one RCCL sum all-reduce of the flat gradient arena."""
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size(self.process_group) > 1:
+        """kvstore-'local' replacement (train_yolov3.py:530): RCCL sum all-reduce of the flat gradient arena.
+        With bucketing (default) the conv-weight range was already queued in ~64 MB pieces during backward();
+        here the handles are awaited and the remaining small range (gamma, beta, head bias) is reduced."""
+        if not self._dp_active():
+            return
+        if self._pending_reduces:
+            for h in self._pending_reduces:
+                h.wait()
+            self._pending_reduces = []
+            lo = self._reduced_from
+            self._reduced_from = self.n_params
+            if lo > 0:                                   # anything before the first bucket (not expected)
+                torch.distributed.all_reduce(self.grads[:lo], group=self.process_group)
+            torch.distributed.all_reduce(self.grads[self.n_weight:], group=self.process_group)
+        else:
             torch.distributed.all_reduce(self.grads, group=self.process_group)
 
     def sgd_step(self, lr, momentum, wd, batch_size, no_wd=False):
