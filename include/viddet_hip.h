@@ -198,6 +198,9 @@ int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, in
                      void* stream);
 int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int B, int K,
                          int64_t inner, int type, void* stream);
+/* 'cat' join (yolo3.py:1108,1136 reshape (B,K,C,h,w)->(B,K*C,h,w)): NHWC [B*K,hw,C] -> [B,hw,K*C];
+ * backward=1 runs the inverse (x = stacked gradient, y = per-frame gradient) */
+int vd_temporal_cat(const float* x, float* y, int B, int K, int64_t hw, int C, int backward, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * YOLO head: decode / filter / NMS / targets / loss

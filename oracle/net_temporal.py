@@ -41,8 +41,9 @@ def temporal_names(k, k_join_pos, bct):
     return stage, block, transition
 
 
-def param_shapes(num_class, k, k_join_pos, bct):
+def param_shapes(num_class, k, k_join_pos, bct, k_join_type='max'):
     S = OrderedDict()
+    cm = k if k_join_type == 'cat' else 1           # channel multiplier of a 'cat' join
     stage, block, transition = temporal_names(k, k_join_pos, bct)
 
     def cell(name, cin, cout, ksz, kd=None):
@@ -60,7 +61,8 @@ def param_shapes(num_class, k, k_join_pos, bct):
             cell(stage(f) + ".body.1", ch // 2, ch, 3)
             f += 1
     A = 3 * (5 + num_class)
-    cin = 1024
+    early = k_join_pos != 'late'
+    cin = 1024 * (cm if early else 1)
     for i, c in enumerate([512, 256, 128]):
         pre, cl = block(i)
 
@@ -84,18 +86,18 @@ def param_shapes(num_class, k, k_join_pos, bct):
             neck_cell("%s.body.%d" % (pre, j), x, co, 1 if j % 2 == 0 else 3)
             x = co
         neck_cell(pre + ".tip", c, 2 * c, 3)
-        S["yolo_outputs.%d.prediction.weight" % i] = (A, 2 * c, 1, 1)
+        S["yolo_outputs.%d.prediction.weight" % i] = (A, 2 * c * (1 if early else cm), 1, 1)
         S["yolo_outputs.%d.prediction.bias" % i] = (A,)
         if i < 2:
             cell(transition(i), c, c // 2, 1)
-            cin = c // 2 + [512, 256][i]
+            cin = c // 2 + [512, 256][i] * (cm if early else 1)
     return S
 
 
-def init_params(num_class, k, k_join_pos, bct, seed=0, obj_bias=0.0):
+def init_params(num_class, k, k_join_pos, bct, seed=0, obj_bias=0.0, k_join_type='max'):
     rng = np.random.default_rng(seed)
     P = OrderedDict()
-    for key, shp in param_shapes(num_class, k, k_join_pos, bct).items():
+    for key, shp in param_shapes(num_class, k, k_join_pos, bct, k_join_type).items():
         if key.endswith("weight"):
             P[key] = rng.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))
             if "prediction" in key:
@@ -116,7 +118,7 @@ def init_params(num_class, k, k_join_pos, bct, seed=0, obj_bias=0.0):
 class TemporalNet(Net):
     def __init__(self, P, num_class, k, k_join_type, k_join_pos, bct='2'):
         super().__init__(P, num_class)
-        assert k > 1 and k_join_type in ('max', 'mean') and k_join_pos in ('early', 'late')
+        assert k > 1 and k_join_type in ('max', 'mean', 'cat') and k_join_pos in ('early', 'late')
         if bct in ('3', '21'):
             assert k_join_pos == 'late'                               # yolo3.py:980
         self.k, self.jt, self.jp, self.bct = k, k_join_type, k_join_pos, bct
@@ -132,6 +134,8 @@ class TemporalNet(Net):
             if name in self.argmax_override:         # the device's winner (differs only at exact-ish ties; cf. ops.leaky)
                 am = self.argmax_override[name]
             y = np.take_along_axis(v5, am[:, None], axis=1)[:, 0]
+        elif self.jt == 'cat':                      # yolo3.py:1108,1136 F.reshape(x,(0,-3,-2)): (B,K,C,h,w)->(B,K*C,h,w)
+            y = v5.reshape((v5.shape[0], K * v5.shape[2]) + v5.shape[3:])
         else:
             y = v5.mean(axis=1)
 
@@ -139,6 +143,8 @@ class TemporalNet(Net):
             if self.jt == 'max':
                 d5 = np.zeros_like(v5)
                 np.put_along_axis(d5, am[:, None], g[:, None], axis=1)
+            elif self.jt == 'cat':
+                d5 = g.reshape(v5.shape)
             else:
                 d5 = np.broadcast_to(g[:, None] / K, v5.shape).copy()
             x.acc(d5.reshape(x.v.shape))

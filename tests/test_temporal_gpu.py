@@ -20,6 +20,8 @@ CFGS = [
     dict(jt="mean", jp="late", bct="21"),
     dict(jt="max", jp="late", bct="2"),
     dict(jt="mean", jp="early", bct="2"),
+    dict(jt="cat", jp="early", bct="2"),
+    dict(jt="cat", jp="late", bct="3"),
 ]
 
 
@@ -27,7 +29,7 @@ def _mk(cfg, c, seed):
     from viddet_amd.model import yolo3_darknet53
     net = yolo3_darknet53(["c%d" % i for i in range(c)], k=3, k_join_type=cfg["jt"], k_join_pos=cfg["jp"],
                           block_conv_type=cfg["bct"])
-    P = OT.init_params(c, 3, cfg["jp"], cfg["bct"], seed=seed, obj_bias=-1.0)
+    P = OT.init_params(c, 3, cfg["jp"], cfg["bct"], seed=seed, obj_bias=-1.0, k_join_type=cfg["jt"])
     assert set(P) == set(net.collect_params().keys()), sorted(set(P) ^ set(net.collect_params().keys()))[:6]
     for k, p in net.collect_params().items():
         assert tuple(P[k].shape) == p.shape, (k, P[k].shape, p.shape)
@@ -123,4 +125,4 @@ def test_temporal_flag_guards():
     with pytest.raises(AssertionError):
         yolo3_darknet53(["a"], k=3, k_join_type="max", k_join_pos="early", block_conv_type="3")   # :980
     with pytest.raises(NotImplementedError):
-        yolo3_darknet53(["a"], k=3, k_join_type="cat", k_join_pos="early")
+        yolo3_darknet53(["a"], k=3)                                           # a join type / position is required

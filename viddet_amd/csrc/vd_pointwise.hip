@@ -150,6 +150,23 @@ __global__ void k_tpool_bwd(const float* __restrict__ dy, const int32_t* __restr
     }
 }
 
+// 'cat' join of the K frames (yolo3.py:1108,1136 F.reshape(x,(0,-3,-2)): (B,K,C,h,w) -> (B,K*C,h,w)):
+// NHWC folded [B*K, hw, C] -> [B, hw, K*C] with channel index k*C + c; 16-byte units; fwd = gather, bwd = scatter
+__global__ void k_tcat(const float* __restrict__ x, float* __restrict__ y, int B, int K, int64_t hw, int C4, int bwd) {
+    const int64_t total = (int64_t)B * K * hw * C4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int64_t px = t % hw;
+        t /= hw;
+        const int k = (int)(t % K);
+        const int64_t b = t / K;
+        const int64_t j = ((b * hw + px) * K + k) * C4 + c;       // position in the stacked tensor
+        if (bwd) reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(x)[j];
+        else reinterpret_cast<f32x4*>(y)[j] = reinterpret_cast<const f32x4*>(x)[i];
+    }
+}
+
 __global__ void k_sgd(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, int64_t n4,
                       int64_t n, float lr, float mom, float wd, float rescale) {
     GRID_STRIDE(i, n4) {
@@ -246,6 +263,14 @@ int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int 
     hipLaunchKernelGGL(k_tpool_bwd, dim3(sblocks((int64_t)B * K * inner)), dim3(256), 0, (hipStream_t)stream, dy, argmax,
                        dx, B, K, inner, type);
     VD_CHECK_LAUNCH("vd_temporal_pool_bwd");
+    return VD_OK;
+}
+
+int vd_temporal_cat(const float* x, float* y, int B, int K, int64_t hw, int C, int backward, void* stream) {
+    VD_REQUIRE(x && y && B > 0 && K > 0 && hw > 0 && C > 0 && C % 4 == 0, "vd_temporal_cat: bad args");
+    hipLaunchKernelGGL(k_tcat, dim3(sblocks((int64_t)B * K * hw * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, B, K, hw,
+                       C / 4, backward);
+    VD_CHECK_LAUNCH("vd_temporal_cat");
     return VD_OK;
 }
 

@@ -243,7 +243,9 @@ class PoolNode:
     """TemporalPooling over the K frames of a window (layers.py:161-205): (B*K, h, w, C) -> (B, h, w, C)."""
 
     def __init__(self, name, src, dst, K, type_):
-        self.name, self.src, self.dst, self.K, self.type = name, src, dst, K, 0 if type_ == 'max' else 1
+        # type 0 = max, 1 = mean, 2 = 'cat' (channel stacking: dst has K * C channels)
+        self.name, self.src, self.dst, self.K = name, src, dst, K
+        self.type = {'max': 0, 'mean': 1, 'cat': 2}[type_]
 
 
 def _feature_name(f):
@@ -300,13 +302,13 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
         pooled = []
         for i, r in enumerate(routes):
             c_, d_ = tensors[r][0], tensors[r][1]
-            pr = T('route%d.pool' % i, c_, d_)
+            pr = T('route%d.pool' % i, c_ * (K if k_join_type == 'cat' else 1), d_)
             nodes.append(PoolNode('pool.route%d' % i, r, pr, K, k_join_type))
             pooled.append(pr)
         routes = pooled
     # neck + heads, deepest first (yolo3.py:1013-1054, 1126-1177)
     A = 3 * (5 + num_class)
-    x, xc = routes[2], 1024
+    x, xc = routes[2], tensors[routes[2]][0]
     heads = []
     conv3 = block_conv_type in ('3', '21')
     for i, c in enumerate([512, 256, 128]):
@@ -346,12 +348,14 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
             xc = cout
         route = x
         tip = add_cell(pre + ".tip", route, 'n%d.tip' % i, c, 2 * c, 3)
-        if late:                                                # yolo3.py:1134-1138: pool the tip over K
-            ptip = T('n%d.tip.pool' % i, 2 * c, d)
+        tipc = 2 * c
+        if late:                                                # yolo3.py:1134-1138: join the tip over K
+            tipc = 2 * c * (K if k_join_type == 'cat' else 1)
+            ptip = T('n%d.tip.pool' % i, tipc, d)
             nodes.append(PoolNode('pool.tip%d' % i, tip, ptip, K, k_join_type))
             tip = ptip
         hd = T('head%d' % i, A, d, round_up(A, 32))
-        nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, 2 * c, A, 1, 1, d, bn=False, head=True))
+        nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, tipc, A, 1, 1, d, bn=False, head=True))
         heads.append(hd)
         if i < 2:
             tr = T('n%d.tr' % i, c // 2, d, fr=nfr)
@@ -652,8 +656,11 @@ class YOLOV3(object):
                          o.shape[1], o.shape[2], n.cu, n.cr)
                 continue
             if isinstance(n, PoolNode):
-                o = bufs[n.dst]
-                prog.add('vd_temporal_pool', bufs[n.src].data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
+                o, xs = bufs[n.dst], bufs[n.src]
+                if n.type == 2:
+                    prog.add('vd_temporal_cat', xs.data_ptr(), o.data_ptr(), B, n.K, xs.shape[1] * xs.shape[2], xs.shape[3], 0)
+                else:
+                    prog.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
                 continue
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
@@ -904,9 +911,12 @@ class YOLOV3(object):
                         o.shape[1], o.shape[2], n.cu, n.cr)
                 continue
             if isinstance(n, PoolNode):
-                o = bufs[n.dst]
-                am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
-                seg.add('vd_temporal_pool', bufs[n.src].data_ptr(), o.data_ptr(), am, B, n.K, o[0].numel(), n.type)
+                o, xs = bufs[n.dst], bufs[n.src]
+                if n.type == 2:
+                    seg.add('vd_temporal_cat', xs.data_ptr(), o.data_ptr(), B, n.K, xs.shape[1] * xs.shape[2], xs.shape[3], 0)
+                else:
+                    am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
+                    seg.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), am, B, n.K, o[0].numel(), n.type)
                 continue
             Ho, Wo = H // n.div_out, W // n.div_out
             M = B * n.fr * Ho * Wo
@@ -1008,12 +1018,14 @@ class YOLOV3(object):
                 assert n.dst in written, n.name
                 dsrc, acc = grad_into(n.src, 0)
                 am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
-                if acc:
-                    tmp = bufs['tmp'][:dsrc.numel()]
-                    seg.add('vd_temporal_pool_bwd', dout.data_ptr(), am, tmp.data_ptr(), B, n.K, dout[0].numel(), n.type)
-                    seg.add('vd_add', dsrc.data_ptr(), tmp.data_ptr(), dsrc.data_ptr(), dsrc.numel())
+                target = bufs['tmp'][:dsrc.numel()] if acc else dsrc
+                if n.type == 2:
+                    seg.add('vd_temporal_cat', dout.data_ptr(), target.data_ptr(), B, n.K, dsrc.shape[1] * dsrc.shape[2],
+                            dsrc.shape[3], 1)
                 else:
-                    seg.add('vd_temporal_pool_bwd', dout.data_ptr(), am, dsrc.data_ptr(), B, n.K, dout[0].numel(), n.type)
+                    seg.add('vd_temporal_pool_bwd', dout.data_ptr(), am, target.data_ptr(), B, n.K, dout[0].numel(), n.type)
+                if acc:
+                    seg.add('vd_add', dsrc.data_ptr(), target.data_ptr(), dsrc.data_ptr(), dsrc.numel())
                 continue
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
@@ -1276,10 +1288,8 @@ def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs
     assert k_join_type in [None, 'max', 'mean', 'cat']
     assert k_join_pos in [None, 'early', 'late']
     if k > 1:
-        if k_join_type == 'cat':
-            raise NotImplementedError("k_join_type='cat' (channel stacking of the K frames) is not built yet")
         if k_join_type is None or k_join_pos is None:
-            raise NotImplementedError("k>1 needs k_join_type (max|mean) and k_join_pos (early|late)")
+            raise NotImplementedError("k>1 needs k_join_type (max|mean|cat) and k_join_pos (early|late)")
     scope = None
     if norm_layer == 'syncbn':
         scope = (norm_kwargs or {}).get('scope', 'all')
