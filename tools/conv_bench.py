@@ -34,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--tile", type=int, default=0, help="forward/dgrad tile variant (0 = heuristic)")
     a = ap.parse_args()
     B = a.batch
     ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
@@ -50,7 +51,7 @@ def main():
         dx = torch.empty_like(x)
         dwp = torch.empty_like(wp)
         flops = 2.0 * cin * cout * k * k * ho * ho * B
-        t_f = timeit(lambda: ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout), a.iters)
+        t_f = timeit(lambda: ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=a.tile), a.iters)
         plans = ops.dgrad_plans(k, pad, s, hin, hin)
         packs = []
         for pl in plans:
@@ -63,7 +64,7 @@ def main():
             for pl, wpk in zip(plans, packs):
                 ops.conv_igemm(dy, wpk, dx, N=B, Hi=ho, Wi=ho, Ci=cout, Hg=pl["Hg"], Wg=pl["Wg"], in_stride=1,
                                taps=pl["taps"], Ho=hin, Wo=hin, Co=cin, ldo=cin, out_stride=s, out_oy=pl["py"],
-                               out_ox=pl["px"])
+                               out_ox=pl["px"], tile=a.tile)
         t_d = timeit(dgrad, a.iters)
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, dwp, ws, k=k, stride=s, pad=pad, Co=cout), a.iters)
         name = "%dx%d s%d %4d->%-4d @%d" % (k, k, s, cin, cout, hin)

@@ -23,11 +23,22 @@
 
 namespace {
 
+#ifndef VD_PD
+#define VD_PD 3
+#endif
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-// a resident page of zeros: the load target of padded / out-of-window rows (see load_a_chunk)
+// a resident page of zeros: the load target of padded / out-of-window rows (see the tap_off select in k_conv_igemm)
 __device__ __attribute__((aligned(64))) float g_zero_page[64];
+
+// intra-wave LDS hand-off: LDS ops of one wave execute in order, so only the compiler must be kept from
+// reordering the accesses (no instruction is generated)
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
 
 struct RowInfo {
     int64_t off;     // element offset of (pixel of tap (0,0,0), channel lc4) in `in`
@@ -105,7 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    f32x4 ra[AP], rb[BP];
+    // register sets = K-steps of global-load latency cover (the 4-wave 128x128 tile has no VGPRs left for a third)
+    constexpr int PD = (VD_PD > 2 && WM * WN == 4 && TM * TN == 4) ? 2 : VD_PD;
+    f32x4 ra[PD][AP], rb[PD][BP];
     int t_tap = 0, c0 = 0;   // k-step cursor of the NEXT tile to load
 
     // tap part of the wave-uniform source offset: refreshed only when the tap changes (every Ci/32 K-steps), so the
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
         return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
     };
     int64_t tap_soff = tap_off(0);
-    auto gload = [&]() {
+    auto gload = [&](f32x4 (&ra)[AP], f32x4 (&rb)[BP]) {
         const int64_t soff = tap_soff + c0;     // wave-uniform
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (XF) {
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
             if (t_tap < p.T) tap_soff = tap_off(t_tap);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -185,40 +198,73 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     };
 
     const int nks = p.T * (p.Ci / BK);
-    gload();
-    lstore(0);
+    gload(ra[0], rb[0]);
+    lstore(0, ra[0], rb[0]);
     __syncthreads();
     // timing probes (VD_IGEMM_PROBE, results are garbage): bit0 skip the global loads, bit1 skip the LDS stores,
     // bit2 skip the per-step barrier
     const int probe = (p.flags >> 8) & 7;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
-        const bool more = (ks + 1 < nks);
-        if (more && !(probe & 1)) gload();
-        compute(cur);
-        if (more && !(probe & 2)) lstore(cur ^ 1);
-        if (!(probe & 4)) __syncthreads();
+    const bool ld = !(probe & 1), st = !(probe & 2), bar = !(probe & 4);
+    // PD K-steps of global-load latency cover with PD register sets (tile t lives in set t % PD): tile ks+PD is
+    // requested while tile ks is multiplied, and the registers of tile ks+1 (requested PD-1 steps earlier, so the
+    // wait is a counted vmcnt that leaves the newer requests in flight) are written to LDS at the end of the
+    // step.  One K-step of cover (~1.9 us of MFMA work) left HBM latency exposed under load.
+    constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;        // unroll so that set and LDS-buffer indices are static
+#pragma unroll
+    for (int d = 1; d < PD; ++d)
+        if (d < nks && ld) gload(ra[d], rb[d]);
+    for (int ks = 0; ks < nks; ks += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ks + u < nks) {
+                if (ks + u + PD < nks && ld) gload(ra[u % PD], rb[u % PD]);
+                compute(u & 1);
+                if (ks + u + 1 < nks && st) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                if (bar) __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue -----------------------------------------------------------------------
+    // The C/D layout has a column per lane and rows across registers: stored directly, one instruction writes two
+    // 128-B row segments of 4 B per lane.  Each wave instead transposes one 32x32 accumulator tile at a time through
+    // a private LDS patch (the operand tiles are dead after the loop's last barrier; LDS ops of one wave execute in
+    // order, so no block barrier) and then owns 4 consecutive columns of 4 rows: scale/shift/LeakyReLU/residual and
+    // the store run on float4s, 8 full 128-B row segments per instruction.  The thin early layers (K = 32..288,
+    // outputs of 0.7 GB) were store-issue bound in the epilogue.
     const bool direct = (p.out_stride == 1 && p.out_oy == 0 && p.out_ox == 0 && p.Ho == p.Hg &&
                          p.Wo == p.Wg);
+    float* stg = smem + wave * (32 * LDS_LD);
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    // float4 path: rows 16-B aligned (wave-uniform; every tensor of the model qualifies, odd pitches fall back)
+    const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
+                        (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 16 == 0)));
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + (lane & 31);
-        const bool cok = col < p.Co;
-        float sc = 1.f, sh = 0.f;
-        if ((p.flags & VD_EPI_AFFINE) && cok) {
-            if (p.scale) sc = p.scale[col];
-            if (p.shift) sh = p.shift[col];
+        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
+        const int nvalid = p.Co - col;                    // columns col .. col+3 that exist (<= 0: none)
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.flags & VD_EPI_AFFINE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nvalid) {
+                    if (p.scale) sc[e] = p.scale[col + e];
+                    if (p.shift) sh[e] = p.shift[col + e];
+                }
         }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            WAVE_SYNC();                                  // the previous tile's reads are done before it is overwritten
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) +
-                                  4 * (lane >> 5);
-                if (!cok || m >= M) continue;
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_LD + (lane & 31)] = acc[mi][ni][r];
+            WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = erow + 8 * i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LDS_LD + ec4);
+                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
+                if (nvalid <= 0 || m >= M) continue;
                 int64_t opix = m;
                 if (!direct) {
                     const unsigned mu = (unsigned)m;
@@ -228,11 +274,27 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                     const int gy = (int)(t - (unsigned)n * (unsigned)p.Hg);
                     opix = (n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
                 }
-                float v = acc[mi][ni][r];
-                if (p.flags & VD_EPI_AFFINE) v = v * sc + sh;
-                if (p.flags & VD_EPI_LEAKY) v = v > 0.f ? v : v * p.slope;
-                if (p.flags & VD_EPI_RESIDUAL) v += p.residual[opix * p.ldr + col];
-                p.out[opix * p.ldo + col] = v;
+                if (p.flags & VD_EPI_AFFINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+                }
+                if (p.flags & VD_EPI_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                }
+                float* dst = p.out + opix * p.ldo + col;
+                if (nvalid >= 4 && vec_ok) {
+                    if (p.flags & VD_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + opix * p.ldr + col);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < nvalid) {
+                            float t = v[e];
+                            if (p.flags & VD_EPI_RESIDUAL) t += p.residual[opix * p.ldr + col + e];
+                            dst[e] = t;
+                        }
+                }
             }
         }
     }
@@ -243,6 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     // puts a column on a lane, so the sums are lane-local over the 16*TM rows, then folded across the two
     // half-waves and the WM waves that share the column.
     if (p.stats_part) {
+        __syncthreads();        // every wave is done with its staging patch
         float* red = smem;      // [WM][BN][2] : the operand tiles are dead after the last barrier of the K loop
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libviddet_hip.so")
+# VD_LIB: developer override for A/B-testing a differently built kernel library (tools/ only)
+LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hip.so")
 
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
