@@ -36,6 +36,11 @@ extern "C" {
 #define VD_EPI_AFFINE    1   /* v = v*scale[c] + shift[c]   (BN-eval fold, or bias with scale==NULL) */
 #define VD_EPI_LEAKY     2   /* v = v>0 ? v : slope*v */
 #define VD_EPI_RESIDUAL  4   /* v += residual[m][c]  (after the activation) */
+/* Arithmetic of the fp32 products (vd_conv_desc.flags / vd_wgrad_desc.flags).  Default: v_mfma_f32_32x32x2_f32, an
+ * exact fp32 fma chain.  VD_MATH_SPLIT: each fp32 operand is split exactly into three bf16 pieces (24 significand
+ * bits) and six of the nine partial products are accumulated in fp32 on the bf16 matrix pipe; the dropped terms are
+ * below 2^-23 of the product (one fp32 rounding).  Storage, accumulation and the epilogue stay fp32. */
+#define VD_MATH_SPLIT    16
 
 const char* vd_last_error(void);
 int vd_version(void);

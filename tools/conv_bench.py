@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tile", type=int, default=0, help="forward/dgrad tile variant (0 = heuristic)")
+    ap.add_argument("--split", action="store_true", help="split-operand fp32 products (VD_MATH_SPLIT)")
+    ap.add_argument("--check", action="store_true", help="print the max/rms error of the forward output against an fp64 CPU conv")
     a = ap.parse_args()
     B = a.batch
     ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
@@ -51,7 +53,7 @@ def main():
         dx = torch.empty_like(x)
         dwp = torch.empty_like(wp)
         flops = 2.0 * cin * cout * k * k * ho * ho * B
-        t_f = timeit(lambda: ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=a.tile), a.iters)
+        t_f = timeit(lambda: ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=a.tile, split=a.split), a.iters)
         plans = ops.dgrad_plans(k, pad, s, hin, hin)
         packs = []
         for pl in plans:
@@ -64,11 +66,18 @@ def main():
             for pl, wpk in zip(plans, packs):
                 ops.conv_igemm(dy, wpk, dx, N=B, Hi=ho, Wi=ho, Ci=cout, Hg=pl["Hg"], Wg=pl["Wg"], in_stride=1,
                                taps=pl["taps"], Ho=hin, Wo=hin, Co=cin, ldo=cin, out_stride=s, out_oy=pl["py"],
-                               out_ox=pl["px"], tile=a.tile)
+                               out_ox=pl["px"], tile=a.tile, split=a.split)
         t_d = timeit(dgrad, a.iters)
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, dwp, ws, k=k, stride=s, pad=pad, Co=cout), a.iters)
         name = "%dx%d s%d %4d->%-4d @%d" % (k, k, s, cin, cout, hin)
-        print("%-28s %9.1f %9.1f %9.1f" % (name, flops / t_f / 1e9, flops / t_d / 1e9, flops / t_w / 1e9))
+        err = ""
+        if a.check:
+            nb = 2
+            ref = torch.nn.functional.conv2d(x[:nb].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), stride=s, padding=pad)
+            got = y[:nb].permute(0, 3, 1, 2).double().cpu()
+            e = (got - ref)
+            err = "  max|err| %.2e rms %.2e (out rms %.2f)" % (e.abs().max(), e.pow(2).mean().sqrt(), ref.pow(2).mean().sqrt())
+        print("%-28s %9.1f %9.1f %9.1f" % (name, flops / t_f / 1e9, flops / t_d / 1e9, flops / t_w / 1e9) + err)
 
 
 if __name__ == "__main__":

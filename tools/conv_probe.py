@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Time ONE forward conv shape (events, median of several launches) — used with VD_IGEMM_PROBE timing probes.
+usage: conv_probe.py cin cout k stride hin [tile] [split] [batch]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from viddet_amd import ops
+
+cin, cout, k, s, hin = [int(v) for v in sys.argv[1:6]]
+tile = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+split = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+B = int(sys.argv[8]) if len(sys.argv) > 8 else 64
+pad = k // 2
+ho = (hin + 2 * pad - k) // s + 1
+x = torch.randn(B, hin, hin, cin, device="cuda")
+w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
+wp = torch.empty(cout, k * k * cin, device="cuda")
+ops.pack_weight_fwd(w, wp, cout)
+y = torch.empty(B, ho, ho, cout, device="cuda")
+ts = []
+for i in range(12):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=tile, split=split)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ts = sorted(ts[2:])
+t = ts[len(ts) // 2]
+print("probe=%s tile=%d split=%d  %.3f ms  %.1f TFLOP/s" % (os.environ.get("VD_IGEMM_PROBE", "0"), tile, split, t,
+                                                        2.0 * cin * cout * k * k * ho * ho * B / t / 1e9))

@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef VD_PROBE
+#define VD_PROBE 0
+#endif
 #ifndef VD_PD
 #define VD_PD 3
 #endif
@@ -40,6 +43,43 @@ __device__ __attribute__((aligned(64))) float g_zero_page[64];
         __builtin_amdgcn_wave_barrier();                         \
     } while (0)
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- split-operand fp32 math (VD_MATH_SPLIT) -------------------------------------------------------------
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (round-to-nearest, the subtractions are
+// exact): three bf16 pieces carry 24 significand bits, |m| <= 2^-8 |x|, |l| <= 2^-16 |x|.  A product a*b is then
+// accumulated in fp32 from the six partial products ah*bh, ah*bm, am*bh, ah*bl, al*bh, am*bm on the bf16 matrix
+// pipe (16x the fp32 MFMA rate); the three dropped terms are below 2^-23 |a*b| and of either sign - the size of
+// one fp32 rounding.  LDS rows hold the three planes back to back, [h: 32 bf16][m: 32][l: 32] = 192 B, and the four
+// 16-B slots of a plane are XOR-swizzled with bits 2..3 of the row: the 16 rows of a ds_read_b128 lane group then
+// fall on 16 distinct slots of the 64 banks, and the two rows a ds_write_b64 lane group stores (8 lanes x 8 B each)
+// fall on the two halves of the 32 write banks (192 B = 16 dwords mod 32) - both conflict-free without padding.
+constexpr int SP_ROWB = 192;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);       // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ void split3(const f32x4 v, uint2& h, uint2& m, uint2& l) {
+    unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = v[2 * q], x1 = v[2 * q + 1];
+        const unsigned hp = pk_bf16(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, hp << 16);
+        const float r1 = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+        const unsigned mp = pk_bf16(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, mp << 16);
+        const float s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+        hh[q] = hp; mm[q] = mp; ll[q] = pk_bf16(s0, s1);
+    }
+    h = make_uint2(hh[0], hh[1]); m = make_uint2(mm[0], mm[1]); l = make_uint2(ll[0], ll[1]);
+}
+
 struct RowInfo {
     int64_t off;     // element offset of (pixel of tap (0,0,0), channel lc4) in `in`
     unsigned mask;   // bit t set <=> tap t of this row lies inside the image / temporal window
@@ -52,7 +92,7 @@ struct RowInfo {
 //   is unconditional (one v_cndmask on the offset, no exec-masked branch per load) and the loop
 //   body is one straight-line stream.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool XF>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
@@ -63,6 +103,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
+    char* As3 = reinterpret_cast<char*>(smem);                  // SP: [2][BM][SP_ROWB]
+    char* Bs3 = As3 + 2 * BM * SP_ROWB;                         // SP: [2][BN][SP_ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -165,6 +207,30 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
         }
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
+        if (SP) {
+            const int wsl = ((((tid & 7) >> 1) ^ ((lrow >> 2) & 3)) << 4) + ((tid & 1) << 3);   // swizzled slot + half
+            char* a3 = As3 + buf * BM * SP_ROWB + wsl;
+            char* b3 = Bs3 + buf * BN * SP_ROWB + wsl;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                uint2 h, m, l;
+                split3(ra[i], h, m, l);
+                char* r = a3 + (lrow + RPP * i) * SP_ROWB;
+                *reinterpret_cast<uint2*>(r) = h;
+                *reinterpret_cast<uint2*>(r + 64) = m;
+                *reinterpret_cast<uint2*>(r + 128) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                uint2 h, m, l;
+                split3(rb[i], h, m, l);
+                char* r = b3 + (lrow + RPP * i) * SP_ROWB;
+                *reinterpret_cast<uint2*>(r) = h;
+                *reinterpret_cast<uint2*>(r + 64) = m;
+                *reinterpret_cast<uint2*>(r + 128) = l;
+            }
+            return;
+        }
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -175,6 +241,35 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
             *reinterpret_cast<f32x4*>(b + (lrow + RPP * i) * LDS_LD + lc4) = rb[i];
     };
     auto compute = [&](int buf) {
+        if (SP) {
+            const char* a3 = As3 + (buf * BM + wm * TM * 32 + (lane & 31)) * SP_ROWB;
+            const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + (lane & 31)) * SP_ROWB;
+            const int swz = (lane >> 2) & 3, hh = lane >> 5;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        fa[mi][q] = *reinterpret_cast<const bf16x8*>(a3 + mi * 32 * SP_ROWB + q * 64 + (((kc * 2 + hh) ^ swz) << 4));
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        fb[ni][q] = *reinterpret_cast<const bf16x8*>(b3 + ni * 32 * SP_ROWB + q * 64 + (((kc * 2 + hh) ^ swz) << 4));
+                }
+                // smallest partial products first
+                constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][QA[t]], fb[ni][QB[t]],
+                                                                                  acc[mi][ni], 0, 0, 0);
+            }
+            return;
+        }
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
         const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
 #pragma unroll
@@ -201,19 +296,41 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
     gload(ra[0], rb[0]);
     lstore(0, ra[0], rb[0]);
     __syncthreads();
-    // timing probes (VD_IGEMM_PROBE, results are garbage): bit0 skip the global loads, bit1 skip the LDS stores,
-    // bit2 skip the per-step barrier
-    const int probe = (p.flags >> 8) & 7;
-    const bool ld = !(probe & 1), st = !(probe & 2), bar = !(probe & 4);
+    // timing probes (compile with -DVD_PROBE=bits; results are garbage): bit0 skip the global loads, bit1 skip the
+    // LDS stores (and the operand split), bit2 skip the per-step barrier
+    constexpr bool ld = !(VD_PROBE & 1), st = !(VD_PROBE & 2), bar = !(VD_PROBE & 4);
     // PD K-steps of global-load latency cover with PD register sets (tile t lives in set t % PD): tile ks+PD is
     // requested while tile ks is multiplied, and the registers of tile ks+1 (requested PD-1 steps earlier, so the
     // wait is a counted vmcnt that leaves the newer requests in flight) are written to LDS at the end of the
     // step.  One K-step of cover (~1.9 us of MFMA work) left HBM latency exposed under load.
+    // The steady-state loop is branch-free: with a guard on any request or store the compiler cannot prove which
+    // requests are still in flight where paths merge, and drains them all (vmcnt(0)) before every new request.
     constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;        // unroll so that set and LDS-buffer indices are static
+    constexpr bool STAGGER = SP && (WM * WN == 8);
+    const bool stag = (wave >> 2) & 1;
 #pragma unroll
     for (int d = 1; d < PD; ++d)
         if (d < nks && ld) gload(ra[d], rb[d]);
-    for (int ks = 0; ks < nks; ks += UN) {
+    int ks = 0;
+    if (nks >= PD) {                                       // (else the prologue requests above were partial)
+        for (; ks + UN + PD <= nks; ks += UN) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (ld) gload(ra[u % PD], rb[u % PD]);
+                // the two waves that share a SIMD (w, w+4) run the step's two phases in opposite order, so one
+                // wave's operand split + LDS stores overlap the other's MFMAs instead of idling the matrix pipe
+                if (STAGGER && stag) {
+                    if (st) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                    compute(u & 1);
+                } else {
+                    compute(u & 1);
+                    if (st) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                }
+                if (bar) __syncthreads();
+            }
+        }
+    }
+    for (; ks < nks; ks += UN) {                           // the last < UN + PD steps, guarded
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (ks + u < nks) {
@@ -356,12 +473,13 @@ const float* zero_page() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool XF>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP = false>
 int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int lds = 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
+    constexpr int lds = SP ? 2 * (BM + BN) * SP_ROWB : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
+    static_assert(lds <= 160 * 1024 && lds >= WM * WN * 32 * LDS_LD * 4, "LDS budget (operand stages; epilogue patches)");
     static bool attr_done = false;
-    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF>;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
@@ -389,8 +507,28 @@ int igemm_resolve_tile(const vd_conv_desc& d) {
 
 int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
 
+// split-operand math (flags & VD_MATH_SPLIT): 8 waves, one workgroup per CU (the three bf16 planes of a
+// double-buffered 256x128 stage fill the 160 KB of LDS)
+int igemm_split_resolve_tile(const vd_conv_desc& d) {
+    int tile = d.tile;
+    if (tile <= 0 || tile > 4) tile = d.Co <= 64 ? 3 : 1;
+    return tile;
+}
+int igemm_split_tile_bm(int tile) { return (tile == 1 || tile == 3) ? 256 : 128; }
+
+template <bool XF>
+int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
+    switch (igemm_split_resolve_tile(d)) {
+        case 1: return launch_igemm<4, 2, 2, 2, XF, true>(d, s);    // 256 x 128, 8 waves of 64x64
+        case 2: return launch_igemm<4, 2, 1, 2, XF, true>(d, s);    // 128 x 128, 8 waves of 32x64
+        case 3: return launch_igemm<4, 2, 2, 1, XF, true>(d, s);    // 256 x  64, 8 waves of 64x32
+        default: return launch_igemm<4, 2, 1, 1, XF, true>(d, s);   // 128 x  64, 8 waves of 32x32
+    }
+}
+
 template <bool XF>
 int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
+    if (d.flags & VD_MATH_SPLIT) return dispatch_igemm_split<XF>(d, s);
     const int tile = igemm_resolve_tile(d);
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, XF>(d, s);   // 128 x 128, 4 waves of 64x64
@@ -754,12 +892,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
     VD_REQUIRE(!d->stats_part || (d->flags & 7) == 0, "vd_conv_igemm: fused BN statistics need a raw (epilogue-free) output");
     hipStream_t s = (hipStream_t)stream;
-    static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
-    if (probe) {
-        vd_conv_desc dd = *d;
-        dd.flags |= (probe & 7) << 8;
-        dispatch_igemm<false>(dd, s);
-    } else if (d->in_scale) dispatch_igemm<true>(*d, s);
+    if (d->in_scale) dispatch_igemm<true>(*d, s);
     else dispatch_igemm<false>(*d, s);
     VD_CHECK_LAUNCH("vd_conv_igemm");
     return VD_OK;
@@ -768,6 +901,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
 int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
     if (!d) return 0;
     const int64_t M = (int64_t)d->N * d->Hg * d->Wg;
+    if (d->flags & VD_MATH_SPLIT) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
     return (int)vd_cdiv(M, igemm_tile_bm(igemm_resolve_tile(*d)));
 }
 

@@ -103,30 +103,58 @@ class Program:
 _TUNE_CACHE = {}
 
 
-def autotune_desc(d, reps=3):
-    """Pick the fastest k_conv_igemm tile variant for one launch descriptor (timed in place on its own buffers
-    with events on the launch stream; cached per problem signature).  Disabled with VD_AUTOTUNE=0.
-    Tuning launches only rewrite buffers every real run rewrites first."""
+def fp32_math():
+    """Arithmetic of the fp32 convolution products (include/viddet_hip.h VD_MATH_SPLIT): 'native' = fp32 MFMA,
+    'split' = three-way bf16 operand split on the bf16 matrix pipe (fp32-accurate), 'auto' = the
+    plan-time autotuner times both per launch record and keeps the faster."""
     import os
+    m = os.environ.get("VD_FP32_MATH", "auto")
+    if m not in ("native", "split", "auto"):
+        raise ValueError("VD_FP32_MATH must be native|split|auto, got %r" % m)
+    return m
+
+
+def _tile_candidates(d, math):
+    """(flags bit, tile) candidates of one launch record."""
+    cands = []
+    if math in ("native", "auto"):
+        if d.Co <= 32:
+            cands += [(0, 7)]
+        elif d.Co <= 64:
+            cands += [(0, 6), (0, 8)]
+        else:
+            cands += [(0, t) for t in (1, 2, 3, 4, 5)]
+    if math in ("split", "auto"):
+        if d.Co <= 64:
+            cands += [(L.MATH_SPLIT, 3), (L.MATH_SPLIT, 4)]
+        else:
+            cands += [(L.MATH_SPLIT, t) for t in (1, 2, 3, 4)]
+    return cands
+
+
+def autotune_desc(d, reps=3):
+    """Pick the fastest k_conv_igemm variant (product arithmetic x tile shape) for one launch descriptor (timed in
+    place on its own buffers with events on the launch stream; cached per problem signature).  VD_AUTOTUNE=0 keeps
+    the kernel's heuristic tile.  Tuning launches only rewrite buffers every real run rewrites first."""
+    import os
+    math = fp32_math()
+    base = d.flags & ~L.MATH_SPLIT
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
+        d.flags = base | (L.MATH_SPLIT if math == "split" else 0)
         return
     lib = L.load()
     s = L.stream_ptr()
-    key = (d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, d.flags, bool(d.in_scale),
+    key = (math, d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, base, bool(d.in_scale),
            bool(d.stats_part))
     if key in _TUNE_CACHE:
-        d.tile = _TUNE_CACHE[key]
+        fl, d.tile = _TUNE_CACHE[key]
+        d.flags = base | fl
         return
-    if d.Co <= 32:
-        cands = [7]
-    elif d.Co <= 64:
-        cands = [6, 8]
-    else:
-        cands = [1, 2, 3, 4, 5]
+    cands = _tile_candidates(d, math)
     best, best_t = cands[0], None
     if len(cands) > 1:
-        for c in cands:
-            d.tile = c
+        for fl, c in cands:
+            d.flags, d.tile = base | fl, c
             L.check(lib.vd_conv_igemm(C.byref(d), s), 'vd_conv_igemm/tune')
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -136,8 +164,8 @@ def autotune_desc(d, reps=3):
             e1.synchronize()
             t = e0.elapsed_time(e1)
             if best_t is None or t < best_t:
-                best, best_t = c, t
-    d.tile = best
+                best, best_t = (fl, c), t
+    d.flags, d.tile = base | best[0], best[1]
     _TUNE_CACHE[key] = best
 
 

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, check, ptr
+from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, check, ptr
 
 
 def round_up(v, m):
@@ -75,7 +75,7 @@ def _set_taps(d, taps):
 # --------------------------------------------------------------------------------------------
 def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo,
                out_stride=1, out_oy=0, out_ox=0, scale=None, shift=None, residual=None, ldr=0,
-               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0):
+               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0, split=False):
     d = ConvDesc()
     d.tile = tile
     d.in_, d.wp, d.out = ptr(x), ptr(wp), ptr(out)
@@ -94,13 +94,15 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
         flags |= EPI_LEAKY
     if residual is not None:
         flags |= EPI_RESIDUAL
+    if split:
+        flags |= MATH_SPLIT
     d.flags, d.slope = flags, slope
     d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
     check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm")
 
 
 def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
-             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0):
+             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0, split=False):
     """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo]."""
     N, Hi, Wi, Ci = x.shape
     Ho = (Hi + 2 * pad - k) // stride + 1
@@ -108,7 +110,7 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     ldo = Co if ldo is None else ldo
     conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
                taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
-               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile)
+               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile, split=split)
     return Ho, Wo
 
 
