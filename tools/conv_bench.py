@@ -68,7 +68,7 @@ def main():
                                taps=pl["taps"], Ho=hin, Wo=hin, Co=cin, ldo=cin, out_stride=s, out_oy=pl["py"],
                                out_ox=pl["px"], tile=a.tile, split=a.split)
         t_d = timeit(dgrad, a.iters)
-        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dwp, ws, k=k, stride=s, pad=pad, Co=cout), a.iters)
+        t_w = timeit(lambda: ops.conv_wgrad(x, dy, dwp, ws, k=k, stride=s, pad=pad, Co=cout, split=a.split), a.iters)
         name = "%dx%d s%d %4d->%-4d @%d" % (k, k, s, cin, cout, hin)
         err = ""
         if a.check:
@@ -77,6 +77,14 @@ def main():
             got = y[:nb].permute(0, 3, 1, 2).double().cpu()
             e = (got - ref)
             err = "  max|err| %.2e rms %.2e (out rms %.2f)" % (e.abs().max(), e.pow(2).mean().sqrt(), ref.pow(2).mean().sqrt())
+            if B <= 8:          # weight gradient against fp64 autograd on the host
+                xd = x.permute(0, 3, 1, 2).double().cpu()
+                wd = w.double().cpu().requires_grad_(True)
+                torch.nn.functional.conv2d(xd, wd, stride=s, padding=pad).backward(dy.permute(0, 3, 1, 2).double().cpu())
+                dw = torch.empty_like(w)
+                ops.unpack_weight(dwp, dw)
+                ew = dw.double().cpu() - wd.grad
+                err += "  wgrad rms err %.2e (rms %.2f)" % (ew.pow(2).mean().sqrt(), wd.grad.pow(2).mean().sqrt())
         print("%-28s %9.1f %9.1f %9.1f" % (name, flops / t_f / 1e9, flops / t_d / 1e9, flops / t_w / 1e9) + err)
 
 

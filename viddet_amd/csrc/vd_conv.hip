@@ -554,8 +554,30 @@ int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_BN = 128, WG_BP = 32;
 
-template <int WM, int WN, int TM, int TN, bool XF>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// One 32-channel x 16-pixel bf16 MFMA operand out of a pixel-major LDS plane [pixel][channels] (wgrad, split
+// math): two ds_read_b64_tr_b16 hardware-transposed reads.  Per 16-lane group, lane 4q+p supplies the address of
+// pixel row q, channels 4p..4p+3, and lane i receives channel i of the 4 pixels - exactly the operand map (lane =
+// channel, elements = 8 consecutive k) without a transposing store.  `base` points at (pixel 16*kc, channel c0) of
+// the plane; 64-B channel chunks are XOR-swizzled with (pixel & 3) so that the 4 pixel rows of a half-wave fall on
+// the 4 quarters of the 64 banks (pitch is a multiple of 256 B).
+__device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c0, int kc, int lane) {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+    const int row0 = 16 * kc + 8 * (g >> 1) + qq;
+    const int colb = (((c0 >> 5) ^ qq) << 6) + ((16 * (g & 1) + 4 * pp) << 1);
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + row0 * pitch + colb));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + (row0 + 4) * pitch + colb));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// second launch bound = waves per SIMD the kernel must fit: two workgroups per CU for the fp32-MFMA tiles (the
+// 8-wave ones must stay within 128 VGPRs), one 8-wave workgroup for the split-math tiles
+template <int WM, int WN, int TM, int TN, bool XF, bool SP>
+__global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
     constexpr int BM = WM * TM * 32;
@@ -569,6 +591,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][WG_BP][BM]      dout
     float* Bs = smem + 2 * WG_BP * BM;        // [2][WG_BP][WG_BN]   in
+    // SP: bf16 planes h/m/l, pixel-major, [2 stages][3][WG_BP][BM] then [2][3][WG_BP][WG_BN]
+    constexpr int APL = WG_BP * BM * 2, BPL = WG_BP * WG_BN * 2;      // bytes of one plane
+    char* As3 = reinterpret_cast<char*>(smem);
+    char* Bs3 = As3 + 2 * 3 * APL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int Ktot = p.T * p.Ci;
@@ -628,8 +654,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    f32x4 ra[APASS], rb[BPASS];
-    auto gload = [&](int64_t pbase) {
+    // register sets (k_conv_igemm has the rationale); the 64x64-per-wave tiles have no VGPRs left for a third
+    constexpr int PD = (SP && TM * TN < 4) ? 3 : 2;
+    f32x4 ra[PD][APASS], rb[PD][BPASS];
+    int64_t next_p = p_begin;                 // first pixel of the next tile to request
+    auto gload = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        const int64_t pbase = next_p;
+        next_p += WG_BP;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int64_t pix = pbase + alpix + AROWS * i;
@@ -670,7 +701,32 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc
             cgx[i] = nx; cgy[i] = ny; cn[i] = nn;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
+        if (SP) {
+            char* a3 = As3 + buf * 3 * APL + (alc & 31) * 2;
+            char* b3 = Bs3 + buf * 3 * BPL + (blc & 31) * 2;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                uint2 h, m, l;
+                split3(ra[i], h, m, l);
+                const int px = alpix + AROWS * i;
+                char* r = a3 + px * (BM * 2) + (((alc >> 5) ^ (px & 3)) << 6);
+                *reinterpret_cast<uint2*>(r) = h;
+                *reinterpret_cast<uint2*>(r + APL) = m;
+                *reinterpret_cast<uint2*>(r + 2 * APL) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                uint2 h, m, l;
+                split3(rb[i], h, m, l);
+                const int px = blpix + BROWS * i;
+                char* r = b3 + px * (WG_BN * 2) + (((blc >> 5) ^ (px & 3)) << 6);
+                *reinterpret_cast<uint2*>(r) = h;
+                *reinterpret_cast<uint2*>(r + BPL) = m;
+                *reinterpret_cast<uint2*>(r + 2 * BPL) = l;
+            }
+            return;
+        }
         float* a = As + buf * WG_BP * BM;
         float* bb = Bs + buf * WG_BP * WG_BN;
 #pragma unroll
@@ -679,6 +735,33 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc
         for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + BROWS * i) * WG_BN + blc) = rb[i];
     };
     auto compute = [&](int buf) {
+        if (SP) {
+            const char* a3 = As3 + buf * 3 * APL;
+            const char* b3 = Bs3 + buf * 3 * BPL;
+#pragma unroll
+            for (int kc = 0; kc < WG_BP / 16; ++kc) {
+                bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        fa[mi][q] = tr_operand(a3 + q * APL, BM * 2, wm * TM * 32 + mi * 32, kc, lane);
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        fb[ni][q] = tr_operand(b3 + q * BPL, WG_BN * 2, wn * TN * 32 + ni * 32, kc, lane);
+                }
+                constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][QA[t]], fb[ni][QB[t]],
+                                                                                  acc[mi][ni], 0, 0, 0);
+            }
+            return;
+        }
         const float* a = As + buf * WG_BP * BM + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
         const float* bb = Bs + buf * WG_BP * WG_BN + (lane >> 5) * WG_BN + wn * TN * 32 + (lane & 31);
 #pragma unroll
@@ -696,19 +779,39 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_wgrad(const vd_wgrad_desc
         }
     };
 
-    const int64_t nsteps = (p_end > p_begin) ? vd_cdiv(p_end - p_begin, WG_BP) : 0;
-    if (nsteps > 0) {
-        gload(p_begin);
-        lstore(0);
+    // same pipeline as k_conv_igemm: PD register sets, branch-free steady state, guarded tail
+    const int nks = (p_end > p_begin) ? (int)vd_cdiv(p_end - p_begin, WG_BP) : 0;
+    constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;
+    if (nks > 0) {
+        gload(ra[0], rb[0]);
+        lstore(0, ra[0], rb[0]);
     }
     __syncthreads();
-    for (int64_t ks = 0; ks < nsteps; ++ks) {
-        const int cur = (int)(ks & 1);
-        const bool more = ks + 1 < nsteps;
-        if (more) gload(p_begin + (ks + 1) * WG_BP);
-        compute(cur);
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
+#pragma unroll
+    for (int d = 1; d < PD; ++d)
+        if (d < nks) gload(ra[d], rb[d]);
+    int ks = 0;
+    if (nks >= PD) {
+        for (; ks + UN + PD <= nks; ks += UN) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                gload(ra[u % PD], rb[u % PD]);
+                compute(u & 1);
+                lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
+    }
+    for (; ks < nks; ks += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ks + u < nks) {
+                if (ks + u + PD < nks) gload(ra[u % PD], rb[u % PD]);
+                compute(u & 1);
+                if (ks + u + 1 < nks) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
     }
 
     float* out = dst + (int64_t)split * p.Co * Ktot;
@@ -739,7 +842,13 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
-int wgrad_bm(const vd_wgrad_desc& d) { return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128); }
+bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & VD_MATH_SPLIT) && d.Co >= 128; }
+int wgrad_bm(const vd_wgrad_desc& d) {
+    if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : 128;
+    return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
+}
+// workgroups resident at once: 2 per CU for the fp32-MFMA tiles, 1 per CU for the split-math tiles (LDS)
+int wgrad_slots(const vd_wgrad_desc& d) { return wgrad_split_math(d) ? 256 : 512; }
 
 int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
@@ -750,10 +859,11 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
     // a 128x256 output split 512 ways moved 134 MB for an 11 GFLOP layer).
     int64_t s = 1;
     double best = -1.0;
-    const int64_t lo = (512 / tiles) > 1 ? (512 / tiles) : 1, hi = vd_cdiv(1536, tiles);
+    const int64_t slots = wgrad_slots(d);
+    const int64_t lo = (slots / tiles) > 1 ? (slots / tiles) : 1, hi = vd_cdiv(3 * slots, tiles);
     for (int64_t c = lo; c <= hi; ++c) {
-        const double x = (double)(tiles * c) / 512.0;
-        const double fill = x / (double)vd_cdiv(tiles * c, 512);
+        const double x = (double)(tiles * c) / (double)slots;
+        const double fill = x / (double)vd_cdiv(tiles * c, slots);
         if (fill > best + 0.02) { best = fill; s = c; }
     }
     const int64_t maxs = vd_cdiv(P, 8 * WG_BP);        // >= 8 k-steps per block
@@ -763,15 +873,17 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
     return (int)s;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool SP = false>
 void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
     constexpr int BM = WM * TM * 32;
-    constexpr int lds = 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
+    constexpr int lds = SP ? 2 * 3 * WG_BP * (BM + WG_BN) * 2 : 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(!SP || BM >= 128, "the 64-B chunk swizzle of the split planes needs rows of >= 256 B");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false, SP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true, SP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
@@ -779,10 +891,10 @@ void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, h
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_do = zp - d.dout;
     if (d.in_scale)
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true, SP>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
                            d, dst, splits, pps, zd_in, zd_do);
     else
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false, SP>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
                            d, dst, splits, pps, zd_in, zd_do);
 }
 
@@ -931,7 +1043,10 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     int64_t pps = vd_cdiv(vd_cdiv(P, splits), WG_BP) * WG_BP;
     float* dst = (splits > 1) ? (float*)ws : d->dwp;
     const int bm = wgrad_bm(*d);
-    if (bm == 32) launch_wgrad<1, 4, 1, 1>(*d, dst, splits, pps, s);
+    if (wgrad_split_math(*d)) {
+        if (bm == 256) launch_wgrad<4, 2, 2, 2, true>(*d, dst, splits, pps, s);   // 256x128, 8 waves of 64x64
+        else launch_wgrad<2, 4, 2, 1, true>(*d, dst, splits, pps, s);             // 128x128, 8 waves of 64x32
+    } else if (bm == 32) launch_wgrad<1, 4, 1, 1>(*d, dst, splits, pps, s);
     else if (bm == 64) launch_wgrad<2, 2, 1, 2>(*d, dst, splits, pps, s);
     else {
         static const int wv = getenv("VD_WGRAD_VARIANT") ? atoi(getenv("VD_WGRAD_VARIANT")) : 2;

@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
         ("in_stride", C.c_int32), ("T", C.c_int32),
         ("dy", C.c_int32 * VD_MAX_TAPS), ("dx", C.c_int32 * VD_MAX_TAPS), ("dz", C.c_int32 * VD_MAX_TAPS),
         ("Kfr", C.c_int32), ("splits", C.c_int32),
-        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float), ("flags", C.c_int32),
     ]
 
 

@@ -169,6 +169,37 @@ def autotune_desc(d, reps=3):
     _TUNE_CACHE[key] = best
 
 
+def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
+    """Product arithmetic of one weight-gradient launch record (fp32 MFMA vs split operands), timed in place."""
+    import os
+    math = fp32_math()
+    d.flags = 0
+    if d.Co < 128 or math == "native":
+        return
+    if math == "split" or os.environ.get("VD_AUTOTUNE", "1") == "0":
+        d.flags = L.MATH_SPLIT
+        return
+    key = ('wgrad', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.Kfr, bool(d.in_scale))
+    if key not in _TUNE_CACHE:
+        lib = L.load()
+        s = L.stream_ptr()
+        best, best_t = 0, None
+        for fl in (0, L.MATH_SPLIT):
+            d.flags = fl
+            L.check(lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s), 'vd_conv_wgrad/tune')
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t:
+                best, best_t = fl, t
+        _TUNE_CACHE[key] = best
+    d.flags = _TUNE_CACHE[key]
+
+
 def autotune_program(prog, reps=3):
     for (fname, fn, args) in prog.recs:
         if fname == 'vd_conv_igemm':
@@ -1101,6 +1132,7 @@ class YOLOV3(object):
             wd_.in_stride = n.stride
             ops._set_taps(wd_, n.taps())
             wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
+            autotune_wgrad(wd_, ws.data_ptr(), ws_bytes)
             seg.hold(wd_)
             if side is not None:
                 e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()

@@ -114,7 +114,7 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     return Ho, Wo
 
 
-def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0):
+def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0, split=False):
     """dwp [Co][T*Ci] (fwd-packed layout) = wgrad(x [N,Hi,Wi,Ci], dout [N,Ho,Wo,Co])."""
     N, Hi, Wi, Ci = x.shape
     _, Ho, Wo, ldd = dout.shape
@@ -125,6 +125,7 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
+    d.flags = MATH_SPLIT if split else 0
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
     if need > ws.numel() * ws.element_size():
@@ -138,7 +139,11 @@ def wgrad_ws_bytes(N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, kd=1, pad_d=0):
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = 1, 0
-    return _lib().vd_conv_wgrad_ws_bytes(C.byref(d))
+    need = 0
+    for fl in (0, MATH_SPLIT):          # the two product arithmetics pick different split counts
+        d.flags = fl
+        need = max(need, _lib().vd_conv_wgrad_ws_bytes(C.byref(d)))
+    return need
 
 
 def pack_weight_fwd(w_oihw, wp, Co_pad):
