@@ -25,6 +25,7 @@ import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # split-operand fp32 products: 6 bf16 MFMAs per fp32 product block
 
 
 def parse():
@@ -204,12 +205,37 @@ def main():
                 w[0] += meta["flops"]; w[1] += ms; w[2] += 1
         ig = agg["vd_conv_igemm"]
         ach = ig[0] / (ig[1] * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-        kname = "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)" if a.dtype == "bf16" else "k_conv_igemm (fp32 v_mfma_f32_32x32x2_f32)"
+        if a.dtype == "bf16":
+            peak = PEAK_BF16_MFMA_TFLOPS
+            kname = "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)"
+            math = None
+        else:
+            # fp32 convolutions run in one of two product arithmetics, chosen per launch record by the plan-time
+            # autotuner: the fp32 MFMA (peak 157.3 TFLOP/s) or split operands (each fp32 value = 3 bf16 pieces, 6
+            # bf16 MFMAs per product block: peak = dense bf16 2500 / 6).  The roofline of the mix is the time an
+            # ideal machine needs, sum_i flops_i / peak_i; `peak` is the equivalent blended rate.
+            ideal_ms, math = 0.0, {"split": [0.0, 0.0, 0], "native": [0.0, 0.0, 0]}
+            for fname, meta, e0, e1 in recs:
+                if fname != "vd_conv_igemm":
+                    continue
+                sp = bool(meta.get("split"))
+                pk = PEAK_SPLIT_TFLOPS if sp else PEAK_FP32_MFMA_TFLOPS
+                ideal_ms += meta["flops"] / (pk * 1e12) * 1e3
+                m_ = math["split" if sp else "native"]
+                m_[0] += meta["flops"]; m_[1] += e0.elapsed_time(e1); m_[2] += 1
+            peak = ig[0] / (ideal_ms * 1e-3) / 1e12
+            kname = ("k_conv_igemm: fp32 in/out/accumulate; products as exact 3-way bf16 split x 6 v_mfma_f32_32x32x16_bf16 "
+                     "(%d launches) or v_mfma_f32_32x32x2_f32 (%d launches)" % (math["split"][2], math["native"][2]))
+            math = {k_: {"launches": v[2], "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
+                         "ms": round(v[1], 3), "peak": PEAK_SPLIT_TFLOPS if k_ == "split" else PEAK_FP32_MFMA_TFLOPS}
+                    for k_, v in math.items()}
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launches": ig[2], "avg_launch_ms": round(ig[1] / ig[2], 4),
                 "algorithmic_gflop_per_launch": round(ig[0] / ig[2] / 1e9, 3)}
+        if math is not None:
+            roof["by_math"] = math
+            roof["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
         roof["algorithmic_mb_per_launch"] = round(sum(m["bytes"] for f_, m, _, _ in recs if f_ == "vd_conv_igemm") / ig[2] / 1e6, 1)
         # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this very
         # command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
@@ -247,7 +273,12 @@ def main():
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),
                        "classes": C, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "syncbn": a.syncbn, "score_filter": (None if train else pass_info),
-                       "hip_graph": bool(a.graphs) and not train},
+                       "hip_graph": bool(a.graphs) and not train,
+                       "fp32_math": (None if a.dtype == "bf16" else
+                                     "VD_FP32_MATH=%s: tensors, accumulation and epilogues fp32; conv products on the fp32 "
+                                     "MFMA or as an exact 3-way bf16 operand split (6 bf16 MFMAs, dropped terms < 2^-23 of "
+                                     "the product; measured error vs fp64 <= the fp32 MFMA's), per launch by the autotuner"
+                                     % os.environ.get("VD_FP32_MATH", "auto"))},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra, "phases": phases,
         }
         if gflop:

@@ -1,0 +1,157 @@
+"""GPU parity of the split-operand fp32 product arithmetic (VD_MATH_SPLIT, include/viddet_hip.h): every
+fp32 operand is split exactly into three bf16 pieces and six partial products are accumulated in fp32 on the
+bf16 matrix pipe.  Checked against the fp64 oracle (oracle/ops.py) with the SAME tolerance as the fp32-MFMA
+kernels (2e-4 abs on O(1) outputs), plus the claim the design rests on: its error against fp64 is not larger
+than the fp32 MFMA's (the fp32 fma chain) on the same data."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as R
+from tests.util import dev, nchw_to_dev_nhwc, dev_nhwc_to_nchw, maxdiff
+from tests.test_conv_gpu import _mk, _packed
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+SHAPES = [  # n, ci, h, w, co, k, stride, pad
+    (2, 64, 8, 8, 128, 3, 1, 1), (6, 128, 8, 8, 256, 3, 1, 1), (3, 32, 13, 11, 96, 1, 1, 0),
+    (2, 64, 17, 15, 160, 3, 2, 1), (5, 96, 21, 19, 320, 3, 1, 1), (1, 64, 19, 19, 255, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_split_fwd_every_tile(tile, shape):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = shape
+    rng, x, wt = _mk(n, ci, h, w, co, k, 70 + tile)
+    res = rng.standard_normal((n, co, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1))
+    sc, sh = rng.uniform(0.5, 1.5, co), rng.standard_normal(co)
+    u = R.conv2d(x, wt, s, p) * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = np.where(u > 0, u, 0.1 * u) + res
+    co_pad = ops.round_up(co, 32)
+    out = torch.full((n, ref.shape[2], ref.shape[3], co_pad), 7.0, device="cuda")
+    scd, shd = torch.zeros(co_pad, device="cuda"), torch.zeros(co_pad, device="cuda")
+    scd[:co], shd[:co] = dev(sc), dev(sh)
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co_pad), out, k=k, stride=s, pad=p, Co=co_pad, ldo=co_pad,
+                 scale=scd, shift=shd, leaky=True, residual=nchw_to_dev_nhwc(res, co_pad), tile=tile, split=True)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 64, 12, 12, 128, 3, 1, 1), (2, 32, 20, 20, 64, 3, 2, 1), (1, 64, 15, 17, 128, 3, 2, 1),
+                                  (3, 256, 13, 13, 128, 1, 1, 0), (2, 96, 9, 9, 75, 1, 1, 0)])
+def test_split_dgrad(case):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 4)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = rng.standard_normal((n, co, ho, wo))
+    dx_ref, _ = R.conv2d_backward(x, wt, dy, s, p)
+    co_pad = ops.round_up(co, 32)
+    dz = nchw_to_dev_nhwc(dy, co_pad)
+    dx = torch.full((n, h, w, ci), 3.0, device="cuda")
+    wdev = dev(wt)
+    for plan in ops.dgrad_plans(k, p, s, h, w):
+        if not plan["taps"]:
+            dx[:, plan["py"]::s, plan["px"]::s, :] = 0
+            continue
+        wp = torch.empty(ci, len(plan["taps"]) * co_pad, device="cuda")
+        ops.pack_weight_dgrad(wdev, wp, Co=co, Co_pad=co_pad, Ci=ci, kd=1, kh=k, kw=k, tap_ids=plan["tap_ids"],
+                              src_packed=False)
+        ops.conv_igemm(dz, wp, dx, N=n, Hi=ho, Wi=wo, Ci=co_pad, Hg=plan["Hg"], Wg=plan["Wg"], in_stride=1,
+                       taps=plan["taps"], Ho=h, Wo=w, Co=ci, ldo=ci, out_stride=s, out_oy=plan["py"],
+                       out_ox=plan["px"], split=True)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(dx), dx_ref) < TOL
+
+
+@pytest.mark.parametrize("case", [
+    (4, 128, 26, 26, 256, 3, 1, 1, 0),   # 256-row tile
+    (2, 64, 15, 17, 128, 3, 2, 1, 7),    # 128-row tile, forced odd split count, ragged pixel ranges
+    (2, 160, 9, 11, 288, 1, 1, 0, 1),    # Ci, Co not multiples of the tiles; single split
+    (3, 32, 14, 14, 128, 3, 1, 1, 0),    # four taps share one 128-wide column tile
+    (2, 64, 13, 13, 64, 3, 1, 1, 0),     # Co < 128: stays on the fp32 MFMA even when the flag is set
+])
+def test_split_wgrad(case):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p, splits = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 6)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = rng.standard_normal((n, co, ho, wo))
+    _, dw_ref = R.conv2d_backward(x, wt, dy, s, p)
+    dwp = torch.empty(co, k * k * ci, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ops.conv_wgrad(nchw_to_dev_nhwc(x), nchw_to_dev_nhwc(dy), dwp, ws, k=k, stride=s, pad=p, Co=co, splits=splits,
+                   split=True)
+    dw = torch.empty(co, ci, k, k, device="cuda")
+    ops.unpack_weight(dwp, dw)
+    torch.cuda.synchronize()
+    assert maxdiff(dw.cpu().numpy(), dw_ref) < TOL * np.sqrt(n * ho * wo)
+
+
+def test_split_error_not_above_fp32_mfma():
+    """The accuracy claim: on a deep reduction (K = 9 * 512) the rms error of the split-operand products against
+    fp64 is no larger than that of the fp32 MFMA (an exact fp32 fma chain) - forward and weight gradient."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k = 4, 512, 13, 13, 256, 3
+    rng, x, wt = _mk(n, ci, h, w, co, k, 99)
+    xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+    x32 = xd.permute(0, 3, 1, 2).double().cpu().numpy()           # the fp32-rounded operands the kernels see
+    w32 = dev(wt).double().cpu().numpy()
+    ref = R.conv2d(x32, w32, 1, 1)
+    err = {}
+    for split in (False, True):
+        out = torch.empty(n, h, w, co, device="cuda")
+        ops.conv_fwd(xd, wp, out, k=k, stride=1, pad=1, Co=co, split=split)
+        torch.cuda.synchronize()
+        e = dev_nhwc_to_nchw(out) - ref
+        err[split] = float(np.sqrt((e ** 2).mean()))
+    assert err[True] <= 1.25 * err[False] + 1e-9, err
+    assert err[True] < 2e-5 * float(np.sqrt((ref ** 2).mean()))
+    # weight gradient: reduction over n*h*w = 676 pixels
+    dy = rng.standard_normal((n, co, h, w))
+    dyd = nchw_to_dev_nhwc(dy)
+    dy32 = dyd.permute(0, 3, 1, 2).double().cpu().numpy()
+    _, dw_ref = R.conv2d_backward(x32, w32, dy32, 1, 1)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for split in (False, True):
+        dwp = torch.empty(co, k * k * ci, device="cuda")
+        ops.conv_wgrad(xd, dyd, dwp, ws, k=k, stride=1, pad=1, Co=co, split=split)
+        dw = torch.empty(co, ci, k, k, device="cuda")
+        ops.unpack_weight(dwp, dw)
+        torch.cuda.synchronize()
+        e = dw.double().cpu().numpy() - dw_ref
+        err[split] = float(np.sqrt((e ** 2).mean()))
+    assert err[True] <= 1.25 * err[False] + 1e-9, err
+
+
+def test_split_fused_bn_statistics():
+    """Fused per-M-tile BatchNorm partial sums out of the split-math epilogue (256- and 128-row tiles)."""
+    from viddet_amd import ops
+    from viddet_amd import lib as L
+    import ctypes as C
+    n, ci, h, w, co, k = 3, 64, 19, 17, 160, 3
+    rng, x, wt = _mk(n, ci, h, w, co, k, 123)
+    ref = R.conv2d(x, wt, 1, 1)
+    M = n * h * w
+    for tile in (1, 2, 3, 4):
+        d = L.ConvDesc()
+        xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+        out = torch.empty(n, h, w, co, device="cuda")
+        part = torch.zeros(64, 2 * co, device="cuda")
+        d.in_, d.wp, d.out = xd.data_ptr(), wp.data_ptr(), out.data_ptr()
+        d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, h, w, ci, h, w, 1
+        ops._set_taps(d, ops.fwd_taps(k, 1))
+        d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo = 1, h, w, co, 1, co
+        d.flags, d.tile, d.stats_part = L.MATH_SPLIT, tile, part.data_ptr()
+        lib = L.load()
+        L.check(lib.vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
+        mt = lib.vd_conv_igemm_mtiles(C.byref(d))
+        torch.cuda.synchronize()
+        assert mt == -(-M // (256 if tile in (1, 3) else 128))
+        s1 = part[:mt, :co].double().sum(0).cpu().numpy()
+        s2 = part[:mt, co:].double().sum(0).cpu().numpy()
+        assert np.abs(s1 - ref.sum((0, 2, 3))).max() < 2e-3
+        assert np.abs(s2 - (ref ** 2).sum((0, 2, 3))).max() < 2e-3 * max(1.0, float((ref ** 2).sum((0, 2, 3)).max()) / 100)

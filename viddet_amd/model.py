@@ -92,6 +92,8 @@ class Program:
                 e0.record()
                 rc = fn(*a, s)
                 e1.record()
+                if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
+                    meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT))
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
