@@ -15,8 +15,9 @@ split = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
 B = int(sys.argv[8]) if len(sys.argv) > 8 else 64
 pad = k // 2
 ho = (hin + 2 * pad - k) // s + 1
-x = torch.randn(B, hin, hin, cin, device="cuda")
-w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
+zero = os.environ.get("VD_PROBE_ZERO") == "1"        # all-zero operands: the DVFS check (same cycles, less power)
+x = torch.zeros(B, hin, hin, cin, device="cuda") if zero else torch.randn(B, hin, hin, cin, device="cuda")
+w = torch.zeros(cout, cin, k, k, device="cuda") if zero else torch.randn(cout, cin, k, k, device="cuda") * 0.05
 wp = torch.empty(cout, k * k * cin, device="cuda")
 ops.pack_weight_fwd(w, wp, cout)
 y = torch.empty(B, ho, ho, cout, device="cuda")

@@ -85,8 +85,15 @@ __global__ __launch_bounds__(1024) void k_bn_sum_partials(const float* __restric
     const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + cx;
     double s = 0.0;
-    if (i < C2)
-        for (int b = sl; b < nblk; b += 16) s += (double)part[(int64_t)b * C2 + i];
+    if (i < C2) {
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {          // four rows in flight, added in row order
+            const float p0 = part[(int64_t)b * C2 + i], p1 = part[(int64_t)(b + 16) * C2 + i];
+            const float p2 = part[(int64_t)(b + 32) * C2 + i], p3 = part[(int64_t)(b + 48) * C2 + i];
+            s += (double)p0; s += (double)p1; s += (double)p2; s += (double)p3;
+        }
+        for (; b < nblk; b += 16) s += (double)part[(int64_t)b * C2 + i];
+    }
     sh[sl][cx] = s;
     __syncthreads();
     if (sl == 0 && i < C2) {

@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef VD_SETPRIO
+#define VD_SETPRIO 1
+#endif
 #ifndef VD_PROBE
 #define VD_PROBE 0
 #endif
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                 }
                 // smallest partial products first
                 constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
+#if VD_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -267,6 +273,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                         for (int ni = 0; ni < TN; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][QA[t]], fb[ni][QB[t]],
                                                                                   acc[mi][ni], 0, 0, 0);
+#if VD_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             return;
         }
@@ -830,15 +839,23 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_w
     }
 }
 
+// Deterministic sum of the split-K slabs: dst[i] = ((ws[0][i] + ws[1][i]) + ws[2][i]) + ...  The additions stay in
+// slab order (bit-reproducible), but the loads of 8 slabs are issued together: thin layers have 100+ slabs of a
+// few thousand floats, and a one-load-at-a-time chain made the kernel latency bound (48 us average).
 __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__ dst, int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const f32x4* src = reinterpret_cast<const f32x4*>(ws);
-    f32x4 a = src[i];
-    for (int s = 1; s < splits; ++s) {
-        const f32x4 v = src[(int64_t)s * n4 + i];
-        a += v;
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + i;
+    f32x4 a = src[0];
+    int s = 1;
+    for (; s + 8 <= splits; s += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(s + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
     }
+    for (; s < splits; ++s) a += src[(int64_t)s * n4];
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
@@ -1057,7 +1074,7 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     VD_CHECK_LAUNCH("vd_conv_wgrad");
     if (splits > 1) {
         const int64_t n4 = (int64_t)d->Co * d->T * d->Ci / 4;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)vd_cdiv(n4, 256)), dim3(256), 0, s, (const float*)ws, d->dwp, n4, splits);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)vd_cdiv(n4, 64)), dim3(64), 0, s, (const float*)ws, d->dwp, n4, splits);
         VD_CHECK_LAUNCH("vd_conv_wgrad/reduce");
     }
     return VD_OK;
