@@ -122,7 +122,7 @@ typedef struct {
     const float* in_scale;  /* optional in-load transform as in vd_conv_desc */
     const float* in_shift;
     float   in_slope;
-    int32_t flags;          /* VD_MATH_SPLIT: split-operand products (Co >= 128; narrower layers stay on the fp32 MFMA) */
+    int32_t flags;          /* VD_MATH_SPLIT: split-operand products (Co >= 64; narrower layers stay on the fp32 MFMA) */
 } vd_wgrad_desc;
 
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d);

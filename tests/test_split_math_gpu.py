@@ -72,7 +72,9 @@ def test_split_dgrad(case):
     (2, 64, 15, 17, 128, 3, 2, 1, 7),    # 128-row tile, forced odd split count, ragged pixel ranges
     (2, 160, 9, 11, 288, 1, 1, 0, 1),    # Ci, Co not multiples of the tiles; single split
     (3, 32, 14, 14, 128, 3, 1, 1, 0),    # four taps share one 128-wide column tile
-    (2, 64, 13, 13, 64, 3, 1, 1, 0),     # Co < 128: stays on the fp32 MFMA even when the flag is set
+    (2, 64, 13, 13, 64, 3, 1, 1, 0),     # 64-row tile (128-B plane rows, two-chunk swizzle)
+    (3, 32, 21, 19, 64, 3, 2, 1, 5),     # same tile, stride 2, ragged
+    (2, 64, 13, 13, 32, 1, 1, 0, 0),     # Co < 64: stays on the fp32 MFMA even when the flag is set
 ])
 def test_split_wgrad(case):
     from viddet_amd import ops

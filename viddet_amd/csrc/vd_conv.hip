@@ -571,11 +571,15 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 // pixel row q, channels 4p..4p+3, and lane i receives channel i of the 4 pixels - exactly the operand map (lane =
 // channel, elements = 8 consecutive k) without a transposing store.  `base` points at (pixel 16*kc, channel c0) of
 // the plane; 64-B channel chunks are XOR-swizzled with (pixel & 3) so that the 4 pixel rows of a half-wave fall on
-// the 4 quarters of the 64 banks (pitch is a multiple of 256 B).
+// the 4 quarters of the 64 banks (pitch a multiple of 256 B); 128-B rows (64 channels) use (pixel >> 1) & 1, which
+// does the same with their two chunks.
+__device__ __forceinline__ int sp_key(int px, int pitch) { return pitch >= 256 ? (px & 3) : ((px >> 1) & 1); }
+
 __device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c0, int kc, int lane) {
     const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
     const int row0 = 16 * kc + 8 * (g >> 1) + qq;
-    const int colb = (((c0 >> 5) ^ qq) << 6) + ((16 * (g & 1) + 4 * pp) << 1);
+    const int key = (pitch >= 256) ? qq : (qq >> 1);          // = sp_key(row0) = sp_key(row0 + 4)
+    const int colb = (((c0 >> 5) ^ key) << 6) + ((16 * (g & 1) + 4 * pp) << 1);
     typedef s16x4 __attribute__((address_space(3))) * lds_p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + row0 * pitch + colb));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + (row0 + 4) * pitch + colb));
@@ -586,7 +590,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c
 // second launch bound = waves per SIMD the kernel must fit: two workgroups per CU for the fp32-MFMA tiles (the
 // 8-wave ones must stay within 128 VGPRs), one 8-wave workgroup for the split-math tiles
 template <int WM, int WN, int TM, int TN, bool XF, bool SP>
-__global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
+__global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
     constexpr int BM = WM * TM * 32;
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_w
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // register sets (k_conv_igemm has the rationale); the 64x64-per-wave tiles have no VGPRs left for a third
-    constexpr int PD = (SP && TM * TN < 4) ? 3 : 2;
+    constexpr int PD = (SP && TM * TN == 2) ? 3 : 2;
     f32x4 ra[PD][APASS], rb[PD][BPASS];
     int64_t next_p = p_begin;                 // first pixel of the next tile to request
     auto gload = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_w
                 uint2 h, m, l;
                 split3(ra[i], h, m, l);
                 const int px = alpix + AROWS * i;
-                char* r = a3 + px * (BM * 2) + (((alc >> 5) ^ (px & 3)) << 6);
+                char* r = a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6);
                 *reinterpret_cast<uint2*>(r) = h;
                 *reinterpret_cast<uint2*>(r + APL) = m;
                 *reinterpret_cast<uint2*>(r + 2 * APL) = l;
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? 2 : WM * WN / 2)) void k_conv_w
                 uint2 h, m, l;
                 split3(rb[i], h, m, l);
                 const int px = blpix + BROWS * i;
-                char* r = b3 + px * (WG_BN * 2) + (((blc >> 5) ^ (px & 3)) << 6);
+                char* r = b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6);
                 *reinterpret_cast<uint2*>(r) = h;
                 *reinterpret_cast<uint2*>(r + BPL) = m;
                 *reinterpret_cast<uint2*>(r + 2 * BPL) = l;
@@ -859,13 +863,13 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
-bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & VD_MATH_SPLIT) && d.Co >= 128; }
+bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & VD_MATH_SPLIT) && d.Co >= 64; }
 int wgrad_bm(const vd_wgrad_desc& d) {
-    if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : 128;
+    if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : (d.Co >= 128 ? 128 : 64);
     return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
 }
 // workgroups resident at once: 2 per CU for the fp32-MFMA tiles, 1 per CU for the split-math tiles (LDS)
-int wgrad_slots(const vd_wgrad_desc& d) { return wgrad_split_math(d) ? 256 : 512; }
+int wgrad_slots(const vd_wgrad_desc& d) { return (wgrad_split_math(d) && d.Co >= 128) ? 256 : 512; }
 
 int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
@@ -895,7 +899,7 @@ void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, h
     constexpr int BM = WM * TM * 32;
     constexpr int lds = SP ? 2 * 3 * WG_BP * (BM + WG_BN) * 2 : 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert(!SP || BM >= 128, "the 64-B chunk swizzle of the split planes needs rows of >= 256 B");
+    static_assert(!SP || BM >= 64, "the 64-B chunk swizzle of the split planes needs rows of >= 128 B");
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false, SP>),
@@ -1061,8 +1065,9 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     float* dst = (splits > 1) ? (float*)ws : d->dwp;
     const int bm = wgrad_bm(*d);
     if (wgrad_split_math(*d)) {
-        if (bm == 256) launch_wgrad<4, 2, 2, 2, true>(*d, dst, splits, pps, s);   // 256x128, 8 waves of 64x64
-        else launch_wgrad<2, 4, 2, 1, true>(*d, dst, splits, pps, s);             // 128x128, 8 waves of 64x32
+        if (bm == 256) launch_wgrad<4, 2, 2, 2, true>(*d, dst, splits, pps, s);        // 256x128, 8 waves of 64x64
+        else if (bm == 128) launch_wgrad<2, 4, 2, 1, true>(*d, dst, splits, pps, s);   // 128x128, 8 waves of 64x32
+        else launch_wgrad<2, 4, 1, 1, true>(*d, dst, splits, pps, s);                  //  64x128, 8 waves of 32x32
     } else if (bm == 32) launch_wgrad<1, 4, 1, 1>(*d, dst, splits, pps, s);
     else if (bm == 64) launch_wgrad<2, 2, 1, 2>(*d, dst, splits, pps, s);
     else {

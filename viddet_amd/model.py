@@ -176,7 +176,7 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     import os
     math = fp32_math()
     d.flags = 0
-    if d.Co < 128 or math == "native":
+    if d.Co < 64 or math == "native":
         return
     if math == "split" or os.environ.get("VD_AUTOTUNE", "1") == "0":
         d.flags = L.MATH_SPLIT
