@@ -22,6 +22,7 @@ import torch
 from viddet_amd import dist as vdist
 from viddet_amd.data import SyntheticDetection, YOLO3VideoInferenceTransform, Loader
 from viddet_amd.metrics import VOCMApMetric
+from viddet_amd.hierarchy import ClassTree, get_class_map, hierarchical_nms, iou  # noqa: F401  (detect_yolo3.py:698-789)
 from viddet_amd.model import yolo3_darknet53
 from train_yolov3 import _list, _bool
 
@@ -169,6 +170,8 @@ def main(argv=None):
     save_predictions(save_dir, dataset, boxes, max_do=FLAGS.max_do)
     if "voc" in FLAGS.metrics and world == 1:
         preds = load_predictions(save_dir, dataset, FLAGS.max_do)
+        if hasattr(dataset, "parents") and hasattr(dataset, "wn_classes"):     # detect_yolo3.py:898-899 (class-tree sets)
+            preds = hierarchical_nms(preds, dataset, level_thresh=FLAGS.hier_level)
         (names, values), = evaluate([VOCMApMetric(iou_thresh=0.5, class_names=dataset.classes)], dataset, preds,
                                     FLAGS.data_shape)
         print("{}={:.4f}".format(names[-1], values[-1]))

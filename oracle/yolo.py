@@ -266,9 +266,10 @@ def bbox_iou_np(a, b, offset=0):
 class VOCMApMetric:
     """metrics/pascalvoc.py:14-259: area-under-PR AP per class, mAP = nanmean."""
 
-    def __init__(self, iou_thresh=0.5, class_names=None):
+    def __init__(self, iou_thresh=0.5, class_names=None, class_map=None):
         self.num = len(class_names)
         self.iou_thresh = iou_thresh
+        self.class_map = class_map                  # pascalvoc.py:37
         self.reset()
 
     def reset(self):
@@ -285,6 +286,8 @@ class VOCMApMetric:
             pred_bbox = pred_bbox[valid_pred, :]
             pred_label = pred_label.flat[valid_pred].astype(int)
             pred_score = pred_score.flat[valid_pred]
+            if self.class_map is not None:                                  # :126-127
+                gt_label = np.expand_dims(np.array([self.class_map[int(l)] for l in gt_label.flat]), axis=0)
             valid_gt = np.where(gt_label.flat >= 0)[0]
             gt_bbox = gt_bbox[valid_gt, :]
             gt_label = gt_label.flat[valid_gt].astype(int)
@@ -356,4 +359,7 @@ class VOCMApMetric:
         aps = [self._average_precision(r, p) for r, p in zip(rec, prec)]
         while len(aps) < self.num:
             aps.append(np.nan)
-        return aps, float(np.nanmean(aps)) if len(aps) else float('nan')
+        m_ap = float(np.nanmean(aps)) if len(aps) else float('nan')
+        if self.class_map:                                                  # :71-80
+            aps = [float('nan') if self.class_map[i] < 0 else aps[self.class_map[i]] for i in range(self.num)]
+        return aps, m_ap

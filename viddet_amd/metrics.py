@@ -30,18 +30,23 @@ class LossMetric:
 
 
 class VOCMApMetric:
-    def __init__(self, iou_thresh=0.5, class_names=None):
+    def __init__(self, iou_thresh=0.5, class_names=None, class_map=None):
+        """class_map (pascalvoc.py:23,37): for a model trained on other labels than the evaluation set's -
+        class_map[eval class] = model class or -1 (detect_yolo3.py get_class_map)."""
         if class_names is None:
             raise ValueError("class_names is required")
         self.class_names = list(class_names)
         self.num = len(self.class_names)
         self.iou_thresh = iou_thresh
+        self.class_map = class_map
         self.reset()
 
     def reset(self):
-        self._npos = np.zeros(self.num, dtype=np.int64)
-        self._scores = [[] for _ in range(self.num)]
-        self._hits = [[] for _ in range(self.num)]      # 1 = true positive, 0 = false positive, -1 = ignored
+        # keyed by label id: with a class_map the model's label set may be larger than the evaluation set's
+        from collections import defaultdict
+        self._npos = defaultdict(int)
+        self._scores = defaultdict(list)
+        self._hits = defaultdict(list)                  # 1 = true positive, 0 = false positive, -1 = ignored
 
     def update(self, pred_bboxes, pred_labels, pred_scores, gt_bboxes, gt_labels, gt_difficults=None):
         """Arguments are lists (or batched arrays) over images, as validate() passes them (train_yolov3.py:487)."""
@@ -51,6 +56,8 @@ class VOCMApMetric:
         for i in range(n):
             pb, pl, ps = np.asarray(pred_bboxes[i]), np.asarray(pred_labels[i]).reshape(-1), np.asarray(pred_scores[i]).reshape(-1)
             gb, gl = np.asarray(gt_bboxes[i]), np.asarray(gt_labels[i]).reshape(-1)
+            if self.class_map is not None:            # pascalvoc.py:126-127: ground-truth ids -> model ids (before the -1 strip)
+                gl = np.array([self.class_map[int(l)] for l in gl])
             keep_p, keep_g = pl >= 0, gl >= 0
             pb, pl, ps = pb.reshape(-1, 4)[keep_p], pl[keep_p].astype(int), ps[keep_p]
             gb, gl = gb.reshape(-1, 4)[keep_g], gl[keep_g].astype(int)
@@ -82,7 +89,7 @@ class VOCMApMetric:
                         taken[g] = True
 
     def _ap(self, c):
-        if self._npos[c] == 0 and not self._scores[c]:
+        if c not in self._npos or (self._npos[c] == 0 and not self._scores[c]):
             return np.nan
         s = np.asarray(self._scores[c])
         h = np.asarray(self._hits[c], dtype=np.int64)[np.argsort(-s, kind="stable")] if len(s) else np.zeros(0, np.int64)
@@ -101,5 +108,14 @@ class VOCMApMetric:
 
     def get(self):
         """-> (names + ['mAP'], values) as the reference returns (pascalvoc.py:51-66)."""
-        aps = [self._ap(c) for c in range(self.num)]
-        return self.class_names + ["mAP"], aps + [float(np.nanmean(aps)) if np.any(~np.isnan(aps)) else float("nan")]
+        n_lab = max([self.num] + [c + 1 for c in self._npos])      # pascalvoc.py:205: every label id seen takes part
+        aps = [self._ap(c) for c in range(n_lab)]
+        m_ap = float(np.nanmean(aps)) if np.any(~np.isnan(aps)) else float("nan")
+        if self.class_map:
+            # pascalvoc.py:71-80: report per evaluation class, mAP untouched.  (For a model class id >= the number of
+            # evaluation names the reference indexes its fixed-size sum_metric list - the mAP slot or an IndexError;
+            # here the mapped class's AP is reported.)
+            vals = [float("nan") if self.class_map[i] < 0 else aps[self.class_map[i]] for i in range(self.num)]
+        else:
+            vals = aps[:self.num]
+        return self.class_names + ["mAP"], vals + [m_ap]
