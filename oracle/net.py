@@ -195,7 +195,8 @@ class Net:
         return Var(y, (up, route), bw)
 
     # ---- whole network: returns the three raw head tensors (stride 32, 16, 8), each (B, A, g, g)
-    def features(self, x_nchw, train):
+    def backbone(self, x_nchw, train):
+        """Darknet-53 trunk -> the three route Vars (features[:15], [15:24], [24:]; wrappers.py:58)."""
         nm = stage_names()
         x = self.cell(nm(0), Var(x_nchw), 3, 1, train)
         f = 1
@@ -209,6 +210,10 @@ class Net:
                 f += 1
             if f in (15, 24, 29):
                 routes.append(x)
+        return routes
+
+    def neck(self, routes, train):
+        """yolo_blocks / transitions / yolo_outputs on three routes (yolo3.py:1126-1177; YOLOV3_noback :1806-1836)."""
         heads = []
         x = routes[2]
         for i in range(3):
@@ -222,6 +227,9 @@ class Net:
                 x = self.upcat(t, routes[1 - i])
         return heads
 
+    def features(self, x_nchw, train):
+        return self.neck(self.backbone(x_nchw, train), train)
+
     def detect(self, x_nchw, nms_thresh=0.45, nms_topk=400, post_nms=100):
         heads = self.features(x_nchw, train=False)
         dets = [Y.yolo_output(h.v, self.C, Y.OUT_ANCHORS[s], Y.OUT_STRIDES[s], training=False)
@@ -232,7 +240,7 @@ class Net:
     def train_step(self, x_nchw, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t, label_smooth=False):
         """Forward in training mode + losses + full backward.  Returns (4 losses (B,), grads dict, heads)."""
         self.G, self.new_running = {}, {}
-        b = x_nchw.shape[0]
+        b = (x_nchw[0] if isinstance(x_nchw, (tuple, list)) else x_nchw).shape[0]
         C = self.C
         heads = self.features(x_nchw, train=True)
         outs = [Y.yolo_output(h.v, C, Y.OUT_ANCHORS[s], Y.OUT_STRIDES[s], training=True) for s, h in enumerate(heads)]
@@ -253,3 +261,11 @@ class Net:
             off += n
         backward(pairs)
         return losses, self.G, [h.v for h in heads]
+
+
+class NoBackNet(Net):
+    """YOLOV3_noback (yolo3.py:1730-1870): the inputs are the three cached backbone feature maps; `x_nchw` of
+    detect()/train_step() is the tuple (x1 (B,256,H/8,W/8), x2 (B,512,H/16,W/16), x3 (B,1024,H/32,W/32))."""
+
+    def features(self, x123, train):
+        return self.neck([Var(np.asarray(t, dtype=np.float64)) for t in x123], train)

@@ -9,7 +9,8 @@ from tests.util import dev, nchw_to_dev_nhwc, dev_nhwc_to_nchw, maxdiff
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 20, 20), (3, 64, 13, 13), (2, 256, 7, 5), (1, 1024, 13, 13), (64, 32, 52, 52)])
+@pytest.mark.parametrize("shape", [(2, 32, 20, 20), (3, 64, 13, 13), (2, 256, 7, 5), (1, 1024, 13, 13), (64, 32, 52, 52),
+                                   (2, 96, 9, 9), (1, 1056, 5, 5)])       # channel counts that do not tile the 256-lane sweep
 def test_bn_train_forward_backward(shape):
     from viddet_amd import ops
     n, c, h, w = shape

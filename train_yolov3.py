@@ -10,7 +10,8 @@ viddet_amd.model.YOLOV3 (hand-written HIP kernels, fixed backward schedule), gra
 one RCCL all-reduce and `--syncbn` becomes a SyncBN collective.
 
 absl is not installed here: argparse re-creates the same flag surface (list flags take comma lists).
-Variants outside the hot path (--temp, --motion_stream, --new_model, --hier, --features_dir, --rnn_pos,
+`--features_dir` trains the neck/heads on cached backbone features (yolo3_no_backbone; features written by
+extract_base_features.py).  Variants outside the hot path (--temp, --motion_stream, --new_model, --hier, --rnn_pos,
 --corr_pos) are accepted and rejected with NotImplementedError like the reference's own guards.
 """
 import argparse
@@ -27,9 +28,10 @@ import numpy as np
 import torch
 
 from viddet_amd import dist as vdist
-from viddet_amd.data import SyntheticDetection, YOLO3VideoTrainTransform, YOLO3VideoInferenceTransform, Loader
+from viddet_amd.data import (SyntheticDetection, YOLO3VideoTrainTransform, YOLO3VideoInferenceTransform, Loader,
+                             FeatureDataset, YOLO3NBVideoTrainTransform, YOLO3NBVideoInferenceTransform)
 from viddet_amd.metrics import VOCMApMetric, LossMetric
-from viddet_amd.model import yolo3_darknet53
+from viddet_amd.model import yolo3_darknet53, yolo3_no_backbone
 from viddet_amd.schedule import LRScheduler, LRSequential
 
 
@@ -112,6 +114,8 @@ def get_dataset(dataset_name, dataset_val_name, save_prefix=""):
     name = dataset_name[0] if len(dataset_name) == 1 else "comb"
     train_ds = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples, seed=FLAGS.seed)
     val_ds = SyntheticDetection(name, num_samples=max(8, FLAGS.synthetic_samples // 4), seed=FLAGS.seed + 1)
+    if FLAGS.features_dir is not None:                 # :177-205 datasets built with features_dir
+        train_ds, val_ds = FeatureDataset(train_ds, FLAGS.features_dir), FeatureDataset(val_ds, FLAGS.features_dir)
     val_metric = VOCMApMetric(iou_thresh=0.5, class_names=val_ds.classes)
     if FLAGS.num_samples < 0:
         FLAGS.num_samples = len(train_ds)
@@ -122,6 +126,12 @@ def get_dataloader(train_dataset, val_dataset, data_shape, batch_size, rank, wor
     """train_yolov3.py:234-286; per-rank batch = batch_size / world (split_and_load, :603-606)."""
     w = h = data_shape
     per_rank = batch_size // world
+    if FLAGS.features_dir is not None:                 # :238-250 the input is pre-saved features
+        train_loader = Loader(train_dataset, YOLO3NBVideoTrainTransform(FLAGS.window[0], w, h, train_dataset.num_class),
+                              per_rank, train=True, shuffle=True, seed=FLAGS.seed, rank=rank, world=world)
+        val_loader = Loader(val_dataset, YOLO3NBVideoInferenceTransform(w, h), per_rank, train=False,
+                            last_batch="discard", rank=rank, world=world)
+        return train_loader, val_loader
     train_loader = Loader(train_dataset, YOLO3VideoTrainTransform(w, h, train_dataset.num_class,
                                                                    np.random.default_rng(FLAGS.seed + rank)),
                           per_rank, train=True, shuffle=True, seed=FLAGS.seed, rank=rank, world=world)
@@ -165,10 +175,18 @@ def get_net(classes, rank_world):
     """train_yolov3.py:332-431 ('ours' definition, darknet53 only)."""
     if FLAGS.network != "darknet53":
         raise NotImplementedError("Backbone CNN model {} not implemented.".format(FLAGS.network))
-    for flag in ("temp", "mult_out", "new_model", "motion_stream", "features_dir", "rnn_pos", "corr_pos"):
+    for flag in ("temp", "mult_out", "new_model", "motion_stream", "rnn_pos", "corr_pos"):
         if getattr(FLAGS, flag):
             raise NotImplementedError("--%s selects a research variant outside the yolo3_darknet53 hot path" % flag)
     k = int(FLAGS.window[0])
+    if FLAGS.features_dir is not None:                 # :335-342
+        net = yolo3_no_backbone(classes, norm_layer="syncbn" if FLAGS.syncbn and rank_world[1] > 1 else None,
+                                norm_kwargs={"scope": FLAGS.syncbn_scope})
+        net.initialize(init="he", seed=FLAGS.seed)
+        start_epoch = FLAGS.start_epoch
+        if FLAGS.resume.strip():
+            start_epoch = resume(net, FLAGS.resume, FLAGS.start_epoch)
+        return net, start_epoch
     net = yolo3_darknet53(classes, pretrained_base=False,
                           norm_layer="syncbn" if FLAGS.syncbn and rank_world[1] > 1 else None,
                           norm_kwargs={"scope": FLAGS.syncbn_scope}, freeze_base=FLAGS.freeze_base,
@@ -185,10 +203,16 @@ def validate(net, val_data, eval_metric, data_shape):
     """train_yolov3.py:434-489."""
     eval_metric.reset()
     net.set_nms(nms_thresh=0.45, nms_topk=400)
-    for x, label, _ in val_data:
-        ids, scores, bboxes = net(torch.from_numpy(x).cuda())
+    for batch in val_data:
+        label = batch[-2]
+        if FLAGS.features_dir is not None:             # :444-461 net(x1, x2, x3)
+            ids, scores, bboxes = net(*[torch.from_numpy(f).cuda() for f in batch[:3]])
+        else:
+            ids, scores, bboxes = net(torch.from_numpy(batch[0]).cuda())
         det_ids, det_scores = ids.cpu().numpy(), scores.cpu().numpy()
-        det_bboxes = np.clip(bboxes.cpu().numpy(), 0, x.shape[-1])              # :477 clip to image size
+        # :458/:477 clip to "the last dim of batch[0]" - the image width, or (as in the reference) the width of the
+        # stride-8 feature map when the batch holds cached features
+        det_bboxes = np.clip(bboxes.cpu().numpy(), 0, batch[0].shape[-1])
         eval_metric.update(det_bboxes, det_ids, det_scores, label[..., :4], label[..., 4:5],
                            label[..., 5:6] if label.shape[-1] > 5 else None)
     return eval_metric.get()
@@ -243,8 +267,12 @@ def train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, st
                 break
             dv = [torch.from_numpy(b).cuda() for b in batch]
             batch_size = dv[0].shape[0] * world
-            # net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)  (:625)
-            obj_loss, center_loss, scale_loss, cls_loss = net(dv[0], dv[6], *dv[1:6])
+            if FLAGS.features_dir is not None:
+                # net(x1, x2, x3, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)  (:595-617)
+                obj_loss, center_loss, scale_loss, cls_loss = net(dv[0], dv[1], dv[2], dv[8], *dv[3:8])
+            else:
+                # net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)  (:625)
+                obj_loss, center_loss, scale_loss, cls_loss = net(dv[0], dv[6], *dv[1:6])
             net.backward()                                  # autograd.backward(sum_losses) (:631)
             net.allreduce_grads()                           # kvstore reduce inside trainer.step (:634)
             num_update += 1

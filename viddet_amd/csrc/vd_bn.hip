@@ -249,8 +249,6 @@ int64_t vd_bn_stats_ws_bytes(int64_t M, int C) { return (int64_t)red_blocks(M) *
 
 int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
     VD_REQUIRE(x && sums && ws && M > 0 && C > 0 && C % 4 == 0, "vd_bn_stats: bad args (C=%d)", C);
-    VD_REQUIRE(C / 4 <= RED_THREADS ? (RED_THREADS % (C / 4) == 0) : ((C / 4) % RED_THREADS == 0),
-               "vd_bn_stats: C/4=%d must divide or be a multiple of %d", C / 4, RED_THREADS);
     const int nb = red_blocks(M);
     if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
         vd_set_error("vd_bn_stats: workspace too small");
@@ -326,8 +324,6 @@ int vd_bn_bwd_reduce(const float* x, const float* dy, const float* scale, const 
                      double* sums2, void* ws, int64_t ws_bytes, void* stream) {
     VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && ws && M > 0 && C % 4 == 0,
                "vd_bn_bwd_reduce: bad args");
-    VD_REQUIRE(C / 4 <= RED_THREADS ? (RED_THREADS % (C / 4) == 0) : ((C / 4) % RED_THREADS == 0),
-               "vd_bn_bwd_reduce: unsupported C=%d", C);
     const int nb = red_blocks(M);
     if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
         vd_set_error("vd_bn_bwd_reduce: workspace too small");

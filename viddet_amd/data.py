@@ -31,7 +31,7 @@ class SyntheticDetection:
         return self._n
 
     def sample_path(self, idx):
-        return "synthetic/%06d.jpg" % idx
+        return "synthetic/s%d_%06d.jpg" % (self._seed, idx)        # the seed keeps train / val file ids apart
 
     def __getitem__(self, idx):
         rng = np.random.default_rng(self._seed * 1000003 + idx)
@@ -94,6 +94,63 @@ class YOLO3VideoTrainTransform:
         return x, obj[0], ctr[0], scl[0], wgt[0], cls[0], gt[0].astype(np.float32)
 
 
+def feature_file_id(img_path):
+    """extract_base_features.py:144-148 (non-VID branch): `<basename without its 4-char extension>`."""
+    return img_path.split("/")[-1][:-4]
+
+
+class FeatureDataset:
+    """A dataset built with `features_dir` (datasets/pascalvoc.py with features_dir set; train_yolov3.py:177-205):
+    samples become (img, f1, f2, f3, label) with the three cached backbone maps read from
+    `<features_dir>/<file id>_F{1,2,3}.npy` as extract_base_features.py wrote them ((C,h,w) fp32 each)."""
+
+    def __init__(self, dataset, features_dir):
+        self.ds, self.dir = dataset, features_dir
+        self.name, self.classes = dataset.name, dataset.classes
+        self.num_class = getattr(dataset, "num_class", len(dataset.classes))
+
+    def __len__(self):
+        return len(self.ds)
+
+    def sample_path(self, idx):
+        return self.ds.sample_path(idx)
+
+    def __getitem__(self, idx):
+        import os
+        img, label = self.ds[idx]
+        fid = feature_file_id(self.ds.sample_path(idx))
+        feats = [np.load(os.path.join(self.dir, "%s_F%d.npy" % (fid, i))) for i in (1, 2, 3)]
+        return (img,) + tuple(feats) + (label,)
+
+
+class YOLO3NBVideoTrainTransform:
+    """transforms.py:353-428: the frames are only used for their size; boxes are resized to the network input and
+    the prefetch targets are generated on the host; the cached features pass through."""
+
+    def __init__(self, k, width, height, num_class):
+        self._k, self._w, self._h, self._c = k, width, height, num_class
+
+    def __call__(self, img, f1, f2, f3, label):
+        h, w = img.shape[-3], img.shape[-2]                       # (h,w,c) or (k,h,w,c)  (transforms.py:399-402)
+        bb = tbbox.resize(label, (w, h), (self._w, self._h))
+        gt = bb[np.newaxis, :, :4]
+        ids = bb[np.newaxis, :, 4:5]
+        obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c)
+        return f1, f2, f3, obj[0], ctr[0], scl[0], wgt[0], cls[0], gt[0].astype(np.float32)
+
+
+class YOLO3NBVideoInferenceTransform:
+    """transforms.py:431-457: features pass through, boxes are resized to (width,height)."""
+
+    def __init__(self, width, height):
+        self._w, self._h = width, height
+
+    def __call__(self, img, f1, f2, f3, label, idx=None):
+        h, w = img.shape[-3], img.shape[-2]
+        bb = tbbox.resize(label, (w, h), (self._w, self._h)).astype(np.float32)
+        return (f1, f2, f3, bb) if idx is None else (f1, f2, f3, bb, idx)
+
+
 def pad_stack(arrs, pad_val=-1.0):
     m = max(a.shape[0] for a in arrs)
     out = np.full((len(arrs), m) + arrs[0].shape[1:], pad_val, dtype=np.float32)
@@ -123,8 +180,11 @@ class Loader:
         for i in range(len(self)):
             chunk = idx[i * self.bs:(i + 1) * self.bs]
             if self.train:
+                # Stack every column, Pad(-1) the trailing gt boxes (train_yolov3.py:238 / :252: 8+1 columns with
+                # cached features, 6+1 with frames)
                 cols = list(zip(*[self.tf(*self.ds[int(j)]) for j in chunk]))
-                yield [np.stack(c) for c in cols[:6]] + [pad_stack(cols[6])]
+                yield [np.stack(c) for c in cols[:-1]] + [pad_stack(cols[-1])]
             else:
+                # (data..., Pad(-1) labels, sample index): 1 data column for frames, 3 for cached features
                 cols = list(zip(*[self.tf(*self.ds[int(j)], int(j)) for j in chunk]))
-                yield np.stack(cols[0]), pad_stack(cols[1]), np.asarray(cols[2])
+                yield tuple(np.stack(c) for c in cols[:-2]) + (pad_stack(cols[-2]), np.asarray(cols[-1]))

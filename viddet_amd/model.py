@@ -317,7 +317,10 @@ def _feature_name(f):
     return "stages.2.%d" % (f - 24)
 
 
-def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2'):
+ROUTE_TENSORS = (('f14', 256, 8), ('f23', 512, 16), ('f28', 1024, 32))   # features[:15], [15:24], [24:] (wrappers.py:58)
+
+
+def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2', noback=False):
     """Node list of YOLOV3T over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258;
     yolo3.py:1003-1054 wiring, :1095-1177 forward).  k>1: the backbone is TimeDistributed (K frames folded
     into the batch, layers.py:241-250); 'early' joins pool each stage output over K, 'late' joins keep K frames
@@ -339,13 +342,19 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
             nm = "%s.model.%s" % (head, idx)
         return nm
 
-    T('in', 3, 1, fr=K)
-    cur = T('f0', 32, 1, fr=K)
-    nodes.append(ConvNode(sname(0), 'in', cur, 3, 32, 3, 1, 1, stem=True, fr=K))
+    routes = []
+    if noback:
+        # YOLOV3_noback (yolo3.py:1730-1840): the three backbone feature maps are the inputs (net(x1, x2, x3)); only
+        # transitions / yolo_blocks / yolo_outputs exist, under the same structural names as in the full network
+        assert K == 1, "YOLOV3_noback has no temporal window"
+        routes = [T(nm, c_, d_) for nm, c_, d_ in ROUTE_TENSORS]
+    else:
+        T('in', 3, 1, fr=K)
+        cur = T('f0', 32, 1, fr=K)
+        nodes.append(ConvNode(sname(0), 'in', cur, 3, 32, 3, 1, 1, stem=True, fr=K))
     f = 1
     div = 1
-    routes = []
-    for nlayer, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
+    for nlayer, ch in zip([] if noback else [1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
         nxt = T('f%d' % f, ch, div * 2, fr=K)
         nodes.append(ConvNode(sname(f), cur, nxt, ch // 2, ch, 3, 2, div, fr=K))
         cur, div, f = nxt, div * 2, f + 1
@@ -436,8 +445,9 @@ class YOLOV3(object):
 
     def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, ignore_iou_thresh=0.7,
                  device="cuda", syncbn_scope=None, process_group=None, k=1, k_join_type=None, k_join_pos=None,
-                 block_conv_type='2'):
+                 block_conv_type='2', noback=False):
         self._classes = list(classes)
+        self.noback = bool(noback)               # YOLOV3_noback: net(x1, x2, x3[, targets]) on cached backbone features
         self._k = k if k and k > 1 else 1
         self._k_join_type, self._k_join_pos, self._block_conv_type = k_join_type, k_join_pos, block_conv_type
         self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
@@ -468,7 +478,9 @@ class YOLOV3(object):
     def _build(self, num_class):
         self.num_class = num_class
         self.nodes, self.tensors, self.head_names = build_graph(num_class, self._k, self._k_join_type,
-                                                                self._k_join_pos, self._block_conv_type)
+                                                                self._k_join_pos, self._block_conv_type,
+                                                                noback=self.noback)
+        self.input_tensors = [nm for nm, _, _ in ROUTE_TENSORS] if self.noback else ['in']
         self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
         # arena layout: [conv weights (fwd-packed) | bn gamma, beta, head bias]  -> wd / no_wd ranges
         off = 0
@@ -656,7 +668,11 @@ class YOLOV3(object):
                 bufs['in'] = torch.empty(B * fr, 3, H, W, device=dev)      # (B,K,3,H,W) folded: frame n = b*K + k
                 continue
             bufs[name] = torch.empty(B * fr, H // div, W // div, ld, device=dev)
-        bufs['col'] = torch.empty(B * self._k, H, W, 32, device=dev)
+        if self.noback:
+            for nm, c_, d_ in ROUTE_TENSORS:                                   # NCHW staging of the three inputs
+                bufs['in:' + nm] = torch.empty(B, c_, H // d_, W // d_, device=dev)
+        else:
+            bufs['col'] = torch.empty(B * self._k, H, W, 32, device=dev)
         if train:
             for n in self.nodes:
                 if isinstance(n, PoolNode) and n.type == 0:
@@ -706,10 +722,26 @@ class YOLOV3(object):
         d.flags, d.slope = flags, LEAKY_SLOPE
         return d
 
+    def _add_input_stage(self, prog, bufs, B, H, W):
+        """Layout change of the network inputs: the frame batch goes NCHW -> 32-wide im2col for the stem; the three
+        cached feature maps of the no-backbone variant go NCHW -> NHWC."""
+        if self.noback:
+            for nm, c_, d_ in ROUTE_TENSORS:
+                prog.add('vd_nchw_to_nhwc', bufs['in:' + nm].data_ptr(), bufs[nm].data_ptr(), B, c_, H // d_, W // d_)
+        else:
+            prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
+
+    def _stage_inputs(self, bufs, x):
+        if self.noback:
+            for (nm, _, _), t in zip(ROUTE_TENSORS, x):
+                bufs['in:' + nm].copy_(t.reshape(bufs['in:' + nm].shape))
+        else:
+            bufs['in'].copy_(x.reshape(bufs['in'].shape))
+
     def _build_infer(self, B, H, W):
         bufs = self._buffers('infer', B, H, W, False)
         prog = Program()
-        prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
+        self._add_input_stage(prog, bufs, B, H, W)
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
@@ -884,9 +916,17 @@ class YOLOV3(object):
             d.tile = _TUNE_CACHE[key]
 
     # ------------------------------------------------------------------ inference
+    def _in_shape(self, x):
+        """(B, H, W) of the image batch a call refers to (the no-backbone inputs are the stride-8/16/32 maps)."""
+        if self.noback:
+            return x[0].shape[0], x[0].shape[-2] * 8, x[0].shape[-1] * 8
+        return x.shape[0], x.shape[-2], x.shape[-1]
+
     def _forward_infer(self, x):
-        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+        B, H, W = self._in_shape(x)
         assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
+        if self.precision == 'bf16' and self.noback:
+            raise NotImplementedError("bf16 inference of the no-backbone variant is not built")
         if self.precision == 'bf16':
             key = ('infer_bf16', B, H, W)
             if key not in self._programs:
@@ -905,7 +945,7 @@ class YOLOV3(object):
                 self._programs[key] = self._build_infer(B, H, W)
             prog, bufs, o = self._programs[key]
             self._refresh_fold()
-        bufs['in'].copy_(x.reshape(bufs['in'].shape))
+        self._stage_inputs(bufs, x)
         if self.use_graphs:
             g = self._graph_cache.get(key)
             if g is None:
@@ -920,6 +960,33 @@ class YOLOV3(object):
             prog.run()
         self.last_rows, self.last_overflow = o['rows'], o['overflow']
         return o['ids'], o['scores'], o['bboxes']
+
+    def extract_features(self, x):
+        """extract_base_features.py:127-130: f1 = features[:15](x), f2 = features[15:24](f1), f3 = features[24:](f2) in
+        inference mode (BatchNorm on running statistics) -> three NCHW fp32 tensors (B,256,H/8,W/8), (B,512,H/16,W/16),
+        (B,1024,H/32,W/32), the inputs of the no-backbone network."""
+        if self.noback or self._k > 1:
+            raise NotImplementedError("extract_features is the per-frame Darknet-53 trunk of the full k=1 network")
+        B, H, W = self._in_shape(x)
+        key = ('features', B, H, W)
+        if key not in self._programs:
+            bufs = self._buffers('infer', B, H, W, False)
+            prog = Program()
+            self._add_input_stage(prog, bufs, B, H, W)
+            last = max(i for i, n in enumerate(self.nodes) if isinstance(n, ConvNode) and n.dst == ROUTE_TENSORS[-1][0])
+            for n in self.nodes[:last + 1]:
+                res = bufs[n.residual] if n.residual else None
+                d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
+                                    leaky=True)
+                prog.hold(d)
+                prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
+            autotune_program(prog)
+            self._programs[key] = (prog, bufs)
+        prog, bufs = self._programs[key]
+        self._refresh_fold()
+        self._stage_inputs(bufs, x)
+        prog.run()
+        return tuple(bufs[nm].permute(0, 3, 1, 2).contiguous() for nm, _, _ in ROUTE_TENSORS)
 
     # ------------------------------------------------------------------ training forward / backward
     def _syncbn(self, n):
@@ -958,7 +1025,7 @@ class YOLOV3(object):
         stats_ws = torch.empty(smax, device=dev)
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
-        seg.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
+        self._add_input_stage(seg, bufs, B, H, W)
 
         def cut(segments, p, fn):
             segments.append(p)
@@ -1158,7 +1225,7 @@ class YOLOV3(object):
                 lo, hi = n.w_off, bucket_hi[0]
                 seg.add_py(self._bucket_launcher(lo, hi, side))
                 bucket_hi[0], bucket_acc[0] = lo, 0
-            if n.stem:
+            if n.stem or n.src in self.input_tensors:     # no gradient flows into the network inputs
                 continue
             # data gradient into d:src
             dsrc, acc = grad_into(n.src, 0)
@@ -1229,7 +1296,7 @@ class YOLOV3(object):
                 s()
 
     def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
-        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+        B, H, W = self._in_shape(x)
         key = ('train', B, H, W)
         if key not in self._programs:
             self._programs[key] = self._build_train(B, H, W)
@@ -1242,7 +1309,7 @@ class YOLOV3(object):
         s['obj'].value, s['ctr'].value, s['scl'].value = obj.data_ptr(), ctr.data_ptr(), scl.data_ptr()
         s['wgt'].value, s['cls'].value = wgt.data_ptr(), cls.data_ptr()
         s['smooth'].value = 1 if self._label_smooth else 0
-        tp['bufs']['in'].copy_(x.reshape(tp['bufs']['in'].shape))
+        self._stage_inputs(tp['bufs'], x)
         self._run_segments(tp['fwd'])
         self._fold_dirty = True            # running stats moved
         self._last_train = tp
@@ -1258,6 +1325,19 @@ class YOLOV3(object):
 
     # ------------------------------------------------------------------ call protocol
     def __call__(self, x, *args):
+        if self.noback:
+            # YOLOV3_noback.hybrid_forward(x1, x2, x3, *args) (yolo3.py:1782): three feature maps, then the targets
+            if len(args) < 2:
+                raise TypeError("the no-backbone network is called as net(x1, x2, x3[, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t])")
+            feats, args = (x, args[0], args[1]), args[2:]
+            for t, (nm, c_, d_) in zip(feats, ROUTE_TENSORS):
+                if t.dim() != 4 or t.shape[1] != c_:
+                    raise ValueError("expected a (B,%d,H/%d,W/%d) feature map, got %s" % (c_, d_, d_, tuple(t.shape)))
+            if len(args) == 0:
+                return self._forward_infer(feats)
+            if len(args) != 6:
+                raise TypeError("training call takes (x1, x2, x3, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)")
+            return self._forward_train(feats, *args)
         if self._k > 1:
             if x.dim() != 5 or x.shape[1] != self._k or x.shape[2] != 3:
                 raise ValueError("expected a (B,%d,3,H,W) window batch, got %s" % (self._k, tuple(x.shape)))
@@ -1361,3 +1441,13 @@ def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs
         for name, p in net.collect_params('stages.*').items():
             p.grad_req = 'null'
     return net
+
+
+def yolo3_no_backbone(classes, norm_layer=None, norm_kwargs=None, **kwargs):
+    """wrappers.py:133-161 -> YOLOV3_noback (yolo3.py:1730-1870): neck + heads on cached Darknet-53 feature maps,
+    called as net(x1, x2, x3[, targets]) with x1 (B,256,H/8,W/8), x2 (B,512,H/16,W/16), x3 (B,1024,H/32,W/32).
+    Parameter names are the transitions.* / yolo_blocks.* / yolo_outputs.* subset of the full network's."""
+    scope = None
+    if norm_layer == 'syncbn':
+        scope = (norm_kwargs or {}).get('scope', 'all')
+    return YOLOV3(classes, syncbn_scope=scope, noback=True, **kwargs)
