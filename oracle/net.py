@@ -240,9 +240,9 @@ class Net:
     def train_step(self, x_nchw, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t, label_smooth=False):
         """Forward in training mode + losses + full backward.  Returns (4 losses (B,), grads dict, heads)."""
         self.G, self.new_running = {}, {}
-        b = (x_nchw[0] if isinstance(x_nchw, (tuple, list)) else x_nchw).shape[0]
         C = self.C
         heads = self.features(x_nchw, train=True)
+        b = heads[0].v.shape[0]           # images the heads predict for (B; B*t with per-frame temporal outputs)
         outs = [Y.yolo_output(h.v, C, Y.OUT_ANCHORS[s], Y.OUT_STRIDES[s], training=True) for s, h in enumerate(heads)]
         box = np.concatenate([o[0] for o in outs], axis=1)
         rawc = np.concatenate([o[1].reshape(b, -1, 2) for o in outs], axis=1)

@@ -23,6 +23,10 @@ def temporal_names(k, k_join_pos, bct):
     """Structural parameter-name prefixes of the k>1 variants (TimeDistributed registers `.model`, Conv `.conv`)."""
     late = k_join_pos == 'late'
     nm0 = stage_names()
+    if k_join_pos == 'tout':
+        # YOLOV3Temporal(t_out=True) (yolo3_temporal.py:313-343): TimeDistributed wrappers are made inside
+        # hybrid_forward, so nothing registers a `.model` child; 3-D / 2+1-D block cells keep the Conv wrapper's `.conv`
+        return nm0, (lambda i: ("yolo_blocks.%d" % i, ".conv" if bct in ('3', '21') else "")), (lambda i: "transitions.%d" % i)
 
     def stage(f):
         head, idx = nm0(f).rsplit(".", 1)
@@ -226,6 +230,49 @@ class TemporalNet(Net):
             if late:
                 tip = self.pool(tip, 'pool.tip%d' % i)                       # :1134-1138
             heads.append(self.head(i, tip, train))
+            if i < 2:
+                t = self.cell(transition(i), x, 1, 1, train)
+                x = self.upcat(t, routes[1 - i])
+        return heads
+
+
+class TemporalOutNet(TemporalNet):
+    """YOLOV3Temporal with t_out=True, corr_d=0 (yolo3_temporal.py:396-470, 492-536): the t frames of a window run
+    through TimeDistributed(stages) (BatchNorm over B*t frames), the detection blocks (TimeDistributed for conv 2,
+    3-D / 2+1-D convs across t otherwise), TimeDistributed(transitions), and TimeDistributed(output): one set of
+    predictions PER FRAME.  Heads come back folded as (B*t, A, g, g), frame index b*t_len + t; Net.detect /
+    Net.train_step on targets folded the same way give the per-frame detections and the per-frame losses, whose
+    mean over all B*t values is what the reference returns (:535)."""
+
+    def __init__(self, P, num_class, t, bct='2'):
+        Net.__init__(self, P, num_class)
+        assert t == 5                                                      # :399
+        self.k, self.jt, self.jp, self.bct = t, None, 'tout', bct
+        self.argmax_override, self.argmax_natural = {}, {}
+
+    def features(self, x_bk, train):
+        stage, block, transition = temporal_names(self.k, 'tout', self.bct)
+        b, K = x_bk.shape[:2]
+        x = self.cell(stage(0), Var(x_bk.reshape((b * K,) + x_bk.shape[2:])), 3, 1, train)
+        f = 1
+        routes = []
+        for nlayer, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
+            x = self.cell(stage(f), x, 3, 2, train)
+            f += 1
+            for _ in range(nlayer):
+                m = self.cell(stage(f) + ".body.0", x, 1, 1, train)
+                x = self.cell(stage(f) + ".body.1", m, 3, 1, train, residual=x)
+                f += 1
+            if f in (15, 24, 29):
+                routes.append(x)
+        heads = []
+        x = routes[2]
+        for i in range(3):
+            pre, cl = block(i)
+            for j in range(5):
+                x = self.neck_cell("%s.body.%d" % (pre, j), cl, x, 1 if j % 2 == 0 else 3, train)
+            tip = self.neck_cell(pre + ".tip", cl, x, 3, train)
+            heads.append(self.head(i, tip, train))                        # TimeDistributed(output): per frame
             if i < 2:
                 t = self.cell(transition(i), x, 1, 1, train)
                 x = self.upcat(t, routes[1 - i])

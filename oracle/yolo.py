@@ -363,3 +363,23 @@ class VOCMApMetric:
         if self.class_map:                                                  # :71-80
             aps = [float('nan') if self.class_map[i] < 0 else aps[self.class_map[i]] for i in range(self.num)]
         return aps, m_ap
+
+
+class VOCMApMetricTemporal:
+    """metrics/pascalvoc.py:262-560 keeps per-offset copies (self._n_pos[t], self._score[t], self._match[t]) of
+    exactly the bookkeeping of VOCMApMetric (:381-450 repeat :116-184 with a [t] index); restated as t accumulators."""
+
+    def __init__(self, t, iou_thresh=0.5, class_names=None):
+        self.t = t
+        self.m = [VOCMApMetric(iou_thresh, class_names) for _ in range(t)]
+
+    def update(self, pred_bboxes, pred_labels, pred_scores, gt_bboxes, gt_labels, gt_difficults=None):
+        for i in range(len(pred_bboxes)):
+            for t in range(np.asarray(pred_bboxes[i]).shape[0]):
+                gd = None if gt_difficults is None or gt_difficults[i] is None else [np.asarray(gt_difficults[i])[t]]
+                self.m[t].update([np.asarray(pred_bboxes[i])[t]], [np.asarray(pred_labels[i])[t]],
+                                 [np.asarray(pred_scores[i])[t]], [np.asarray(gt_bboxes[i])[t]],
+                                 [np.asarray(gt_labels[i])[t]], gd)
+
+    def get(self):
+        return [m.get() for m in self.m]

@@ -141,3 +141,25 @@ def test_voc_map_with_class_map_product_vs_oracle():
     big = VOCMApMetric(0.5, class_names=["e0", "e1"], class_map=[5, -1])
     big.update([np.array([[0., 0., 10., 10.]])], [np.array([5.])], [np.array([0.9])], [np.array([[0., 0., 10., 10.]])], [np.array([0.])])
     assert big.get()[1][0] == 1.0 and np.isnan(big.get()[1][1])
+
+
+def test_voc_map_temporal_product_vs_oracle():
+    """VOCMApMetricTemporal (metrics/pascalvoc.py:262-560): per-offset accumulators over (B, t, N, .) inputs."""
+    from oracle import yolo as Y
+    from viddet_amd.metrics import VOCMApMetricTemporal
+    rng = np.random.default_rng(9)
+    T_, names = 3, ["a", "b", "c"]
+    prod, orac = VOCMApMetricTemporal(T_, 0.5, class_names=names), Y.VOCMApMetricTemporal(T_, 0.5, class_names=names)
+    for _ in range(4):
+        B, N, M = 2, 7, 3
+        g = rng.uniform(0, 60, (B, T_, M, 2)); gtb = np.concatenate([g, g + rng.uniform(8, 30, (B, T_, M, 2))], -1)
+        gtl = rng.integers(-1, 3, (B, T_, M, 1)).astype(float)
+        pb = np.concatenate([gtb, gtb[:, :, :1].repeat(N - M, 2) + rng.normal(0, 5, (B, T_, N - M, 4))], 2) + rng.normal(0, 1.5, (B, T_, N, 4))
+        pl = rng.integers(-1, 3, (B, T_, N, 1)).astype(float)
+        ps = rng.uniform(0, 1, (B, T_, N, 1))
+        prod.update(pb, pl, ps, gtb, gtl)
+        orac.update(pb, pl, ps, gtb, gtl)
+    nm, vals = prod.get()
+    assert nm[:4] == ["a t=0/3", "b t=0/3", "c t=0/3", "mAP t=0/3"] and len(nm) == len(vals) == T_ * 4
+    for t, (aps, mean) in enumerate(orac.get()):
+        assert np.allclose(vals[4 * t:4 * t + 3], aps, equal_nan=True) and np.isclose(vals[4 * t + 3], mean, equal_nan=True)

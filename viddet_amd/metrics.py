@@ -119,3 +119,35 @@ class VOCMApMetric:
         else:
             vals = aps[:self.num]
         return self.class_names + ["mAP"], vals + [m_ap]
+
+
+class VOCMApMetricTemporal:
+    """metrics/pascalvoc.py:262-560: one VOC mAP accumulator per frame offset of a t-frame window (--mult_out).
+    update() takes (B, t, N, .) predictions and (B, t, M, .) ground truth; get() lists, offset by offset,
+    '<class> t=<offset>/<t>' ... 'mAP t=<offset>/<t>' with their values."""
+
+    def __init__(self, t, iou_thresh=0.5, class_names=None, class_map=None):
+        self.t = int(t)
+        self._per_t = [VOCMApMetric(iou_thresh, class_names, class_map) for _ in range(self.t)]
+        self.class_names = self._per_t[0].class_names
+
+    def reset(self):
+        for m in self._per_t:
+            m.reset()
+
+    def update(self, pred_bboxes, pred_labels, pred_scores, gt_bboxes, gt_labels, gt_difficults=None):
+        n = len(pred_bboxes)
+        for i in range(n):
+            pb, pl, ps = np.asarray(pred_bboxes[i]), np.asarray(pred_labels[i]), np.asarray(pred_scores[i])
+            gb, gl = np.asarray(gt_bboxes[i]), np.asarray(gt_labels[i])
+            gd = None if gt_difficults is None or gt_difficults[i] is None else np.asarray(gt_difficults[i])
+            for t in range(pb.shape[0]):                                     # :381 for t in range(pred_bbox_t.shape[0])
+                self._per_t[t].update([pb[t]], [pl[t]], [ps[t]], [gb[t]], [gl[t]], None if gd is None else [gd[t]])
+
+    def get(self):
+        names, values = [], []
+        for t, m in enumerate(self._per_t):
+            nm, vals = m.get()
+            names += ["%s t=%d/%d" % (x, t, self.t) for x in nm]                # :326
+            values += list(vals)
+        return names, values

@@ -320,7 +320,8 @@ def _feature_name(f):
 ROUTE_TENSORS = (('f14', 256, 8), ('f23', 512, 16), ('f28', 1024, 32))   # features[:15], [15:24], [24:] (wrappers.py:58)
 
 
-def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2', noback=False):
+def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2', noback=False,
+                temporal_out=False):
     """Node list of YOLOV3T over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258;
     yolo3.py:1003-1054 wiring, :1095-1177 forward).  k>1: the backbone is TimeDistributed (K frames folded
     into the batch, layers.py:241-250); 'early' joins pool each stage output over K, 'late' joins keep K frames
@@ -328,8 +329,12 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
     the tips right before the prediction convs (:1134-1138)."""
     nodes, tensors = [], OrderedDict()     # tensors[name] = (channels, div, pitch, frames)
     K = k if k and k > 1 else 1
-    late = K > 1 and k_join_pos == 'late'
-    td = ".model" if K > 1 else ""         # TimeDistributed registers its child as `.model`
+    # temporal_out = YOLOV3Temporal with t_out (yolo3_temporal.py:396-470, corr_d = 0): every one of the t frames runs
+    # through the backbone, the detection blocks (per frame, or 3-D / 2+1-D convs across the t axis) and its OWN
+    # prediction convs - no join; TimeDistributed wrappers are created inside hybrid_forward there, so parameter
+    # names carry no `.model`
+    late = K > 1 and (k_join_pos == 'late' or temporal_out)
+    td_names = K > 1 and not temporal_out
 
     def T(name, c, div, ld=None, fr=1):
         tensors[name] = (c, div, c if ld is None else ld, fr)
@@ -337,7 +342,7 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
 
     def sname(f):
         nm = _feature_name(f)
-        if K > 1:
+        if td_names:
             head, idx = nm.rsplit(".", 1)
             nm = "%s.model.%s" % (head, idx)
         return nm
@@ -385,7 +390,7 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
         d = 32 >> i
         if conv3:
             pre, cell = "yolo_blocks.%d" % i, ".conv"           # Conv wrapper registers `.conv` (layers.py:135-158)
-        elif late:
+        elif late and td_names:
             pre, cell = "yolo_blocks.%d.model" % i, ""           # TimeDistributed(block)
         else:
             pre, cell = "yolo_blocks.%d" % i, ""
@@ -419,18 +424,19 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
         route = x
         tip = add_cell(pre + ".tip", route, 'n%d.tip' % i, c, 2 * c, 3)
         tipc = 2 * c
-        if late:                                                # yolo3.py:1134-1138: join the tip over K
+        if late and not temporal_out:                           # yolo3.py:1134-1138: join the tip over K
             tipc = 2 * c * (K if k_join_type == 'cat' else 1)
             ptip = T('n%d.tip.pool' % i, tipc, d)
             nodes.append(PoolNode('pool.tip%d' % i, tip, ptip, K, k_join_type))
             tip = ptip
-        hd = T('head%d' % i, A, d, round_up(A, 32))
-        nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, tipc, A, 1, 1, d, bn=False, head=True))
+        hfr = K if temporal_out else 1                          # per-frame predictions (TimeDistributed(output))
+        hd = T('head%d' % i, A, d, round_up(A, 32), fr=hfr)
+        nodes.append(ConvNode("yolo_outputs.%d.prediction" % i, tip, hd, tipc, A, 1, 1, d, bn=False, head=True, fr=hfr))
         heads.append(hd)
         if i < 2:
             tr = T('n%d.tr' % i, c // 2, d, fr=nfr)
-            nodes.append(ConvNode("transitions.%d%s" % (i, ".model" if late else ""), route, tr, c, c // 2, 1, 1, d,
-                                  fr=nfr))
+            nodes.append(ConvNode("transitions.%d%s" % (i, ".model" if (late and td_names) else ""), route, tr, c, c // 2,
+                                  1, 1, d, fr=nfr))
             rt = routes[1 - i]
             rc = tensors[rt][0]
             cat = T('n%d.cat' % i, c // 2 + rc, d // 2, fr=nfr)
@@ -445,8 +451,10 @@ class YOLOV3(object):
 
     def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, ignore_iou_thresh=0.7,
                  device="cuda", syncbn_scope=None, process_group=None, k=1, k_join_type=None, k_join_pos=None,
-                 block_conv_type='2', noback=False):
+                 block_conv_type='2', noback=False, temporal_out=False):
         self._classes = list(classes)
+        self.temporal_out = bool(temporal_out)   # YOLOV3Temporal(t_out=True): per-frame detections / losses
+        self._grad_scale = 1.0                   # d(reported loss)/d(sum of per-sample losses), see _forward_train
         self.noback = bool(noback)               # YOLOV3_noback: net(x1, x2, x3[, targets]) on cached backbone features
         self._k = k if k and k > 1 else 1
         self._k_join_type, self._k_join_pos, self._block_conv_type = k_join_type, k_join_pos, block_conv_type
@@ -479,7 +487,8 @@ class YOLOV3(object):
         self.num_class = num_class
         self.nodes, self.tensors, self.head_names = build_graph(num_class, self._k, self._k_join_type,
                                                                 self._k_join_pos, self._block_conv_type,
-                                                                noback=self.noback)
+                                                                noback=self.noback, temporal_out=self.temporal_out)
+        self._head_frames = self._k if self.temporal_out else 1
         self.input_tensors = [nm for nm, _, _ in ROUTE_TENSORS] if self.noback else ['in']
         self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
         # arena layout: [conv weights (fwd-packed) | bn gamma, beta, head bias]  -> wd / no_wd ranges
@@ -764,25 +773,26 @@ class YOLOV3(object):
             prog.hold(d)
             prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
         grids = self._grid(H, W)
+        Bh = B * self._head_frames           # images the decode / NMS see (B*t with per-frame predictions)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
-                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+                                STRIDES[::-1], ANCHORS[::-1], Bh, self.num_class)
         P = 3 * sum(g * g for g in grids)
         cap = min(self.num_class * P, 1 << 18)
-        o = dict(cand_score=torch.empty(B, cap, device=self.device),
-                 cand_row=torch.empty(B, cap, dtype=torch.int32, device=self.device),
-                 counts=torch.zeros(B, dtype=torch.int32, device=self.device),
-                 ids=torch.empty(B, self.post_nms, 1, device=self.device),
-                 scores=torch.empty(B, self.post_nms, 1, device=self.device),
-                 bboxes=torch.empty(B, self.post_nms, 4, device=self.device),
-                 rows=torch.empty(B, self.post_nms, dtype=torch.int32, device=self.device),
-                 overflow=torch.zeros(B, dtype=torch.int32, device=self.device))
+        o = dict(cand_score=torch.empty(Bh, cap, device=self.device),
+                 cand_row=torch.empty(Bh, cap, dtype=torch.int32, device=self.device),
+                 counts=torch.zeros(Bh, dtype=torch.int32, device=self.device),
+                 ids=torch.empty(Bh, self.post_nms, 1, device=self.device),
+                 scores=torch.empty(Bh, self.post_nms, 1, device=self.device),
+                 bboxes=torch.empty(Bh, self.post_nms, 4, device=self.device),
+                 rows=torch.empty(Bh, self.post_nms, dtype=torch.int32, device=self.device),
+                 overflow=torch.zeros(Bh, dtype=torch.int32, device=self.device))
         prog.hold(hd, o)
         prog.add('vd_yolo_decode_filter', C.byref(hd), 0.01, o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
                  o['counts'].data_ptr())
         prog.add('vd_nms_topk', C.byref(hd), o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
                  o['counts'].data_ptr(), float(self.nms_thresh), int(self.nms_topk), int(self.post_nms),
                  o['ids'].data_ptr(), o['scores'].data_ptr(), o['bboxes'].data_ptr(), o['rows'].data_ptr(),
-                 o['overflow'].data_ptr(), 4 * B)
+                 o['overflow'].data_ptr(), 4 * Bh)
         autotune_program(prog)
         return prog, bufs, o
 
@@ -925,8 +935,8 @@ class YOLOV3(object):
     def _forward_infer(self, x):
         B, H, W = self._in_shape(x)
         assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
-        if self.precision == 'bf16' and self.noback:
-            raise NotImplementedError("bf16 inference of the no-backbone variant is not built")
+        if self.precision == 'bf16' and (self.noback or self.temporal_out):
+            raise NotImplementedError("bf16 inference of the no-backbone / per-frame-output variants is not built")
         if self.precision == 'bf16':
             key = ('infer_bf16', B, H, W)
             if key not in self._programs:
@@ -959,6 +969,9 @@ class YOLOV3(object):
         else:
             prog.run()
         self.last_rows, self.last_overflow = o['rows'], o['overflow']
+        if self.temporal_out:                    # (B, t, 100, .) as TimeDistributed(output) stacks them
+            K = self._k
+            return (o['ids'].view(B, K, -1, 1), o['scores'].view(B, K, -1, 1), o['bboxes'].view(B, K, -1, 4))
         return o['ids'], o['scores'], o['bboxes']
 
     def extract_features(self, x):
@@ -1081,9 +1094,9 @@ class YOLOV3(object):
         # loss (targets are late-bound)
         grids = self._grid(H, W)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
-                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+                                STRIDES[::-1], ANCHORS[::-1], B * self._head_frames, self.num_class)
         slots = dict(gt=Slot(), M=Slot(), obj=Slot(), ctr=Slot(), scl=Slot(), wgt=Slot(), cls=Slot(), smooth=Slot())
-        losses = torch.zeros(B, 4, device=dev)
+        losses = torch.zeros(B * self._head_frames, 4, device=dev)
         dh = (C.c_void_p * 3)(*[bufs['d:' + h].data_ptr() for h in self.head_names])
         lws = torch.empty(max(16, ops.yolo_loss_ws_bytes(hd)), dtype=torch.uint8, device=dev)
         seg.hold(hd, dh, lws)
@@ -1303,6 +1316,14 @@ class YOLOV3(object):
         tp = self._programs[key]
         f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         gt, obj, ctr, scl, wgt, cls = [f32(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
+        if self.temporal_out:
+            # yolo3_temporal.py:521-533: frame t of window b is matched against ITS targets (args sliced on axis 1);
+            # folded here as image b*t_len + t, the order the frames already have
+            K = self._k
+            for t in (gt, obj, ctr, scl, wgt, cls):
+                if t.dim() < 3 or t.shape[0] != B or t.shape[1] != K:
+                    raise ValueError("per-frame targets are (B,%d,...) tensors, got %s" % (K, tuple(t.shape)))
+            gt, obj, ctr, scl, wgt, cls = [t.reshape((B * K,) + tuple(t.shape[2:])) for t in (gt, obj, ctr, scl, wgt, cls)]
         tp['live'] = (gt, obj, ctr, scl, wgt, cls)
         s = tp['slots']
         s['gt'].value, s['M'].value = gt.data_ptr(), int(gt.shape[1])
@@ -1314,6 +1335,14 @@ class YOLOV3(object):
         self._fold_dirty = True            # running stats moved
         self._last_train = tp
         L_ = tp['losses']
+        if self.temporal_out:
+            # :535 [F.mean(F.concat(*l, dim=0)) for l in losses]: four scalars, means over the B*t per-frame losses.
+            # backward() computes the gradient of the SUM of the per-frame losses; the 1/(B*t) of the mean is a
+            # common factor of the whole gradient and is applied with the optimiser's rescale (sgd_step)
+            self._grad_scale = 1.0 / float(L_.shape[0])
+            m = L_.mean(dim=0)
+            return m[0], m[1], m[2], m[3]
+        self._grad_scale = 1.0
         return L_[:, 0], L_[:, 1], L_[:, 2], L_[:, 3]
 
     def backward(self):
@@ -1387,7 +1416,7 @@ class YOLOV3(object):
     def sgd_step(self, lr, momentum, wd, batch_size, no_wd=False):
         """gluon.Trainer('sgd').step(batch_size) (train_yolov3.py:527-530,634); wd_mult=0 on gamma/beta/bias
         with --no_wd (:495-497)."""
-        rescale = 1.0 / float(batch_size)
+        rescale = self._grad_scale / float(batch_size)
         nw = self.n_weight
         ops.sgd_momentum(self.weights[:nw], self.grads[:nw], self.momentum_buf[:nw], lr, momentum, wd, rescale)
         ops.sgd_momentum(self.weights[nw:], self.grads[nw:], self.momentum_buf[nw:], lr, momentum,
@@ -1417,10 +1446,22 @@ class YOLOV3(object):
 
 
 def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs=None, freeze_base=False,
-                    k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', **kwargs):
+                    k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', temporal=False, t_out=False,
+                    corr_d=None, **kwargs):
     """wrappers.py:9-110 -> YOLOV3T (yolo3.py:959-1054).  norm_layer='syncbn' (the reference passes
-    SyncBatchNorm) selects the SyncBN collective.  k>1 builds the temporal-window variants."""
+    SyncBatchNorm) selects the SyncBN collective.  k>1 builds the temporal-window variants; `t_out=True`
+    (--temp --mult_out) builds YOLOV3Temporal with per-frame outputs (yolo3_temporal.py:286-555, t = k = 5)."""
     k = 1 if k is None else int(k)
+    if temporal or t_out:                                         # wrappers.py:96-98
+        if corr_d:
+            raise NotImplementedError("YOLOV3Temporal with a correlation branch (corr_d) is outside the built scope")
+        if not t_out:
+            raise NotImplementedError("YOLOV3Temporal without per-frame outputs (the strided 2+1-D side branches, "
+                                      "yolo3_temporal.py:431-441) is not built; use t_out=True")
+        assert k == 5, "Currently only support t=5 but will increase to more later"        # yolo3_temporal.py:399
+        assert block_conv_type in ('2', '3', '21')
+        scope = (norm_kwargs or {}).get('scope', 'all') if norm_layer == 'syncbn' else None
+        return YOLOV3(classes, syncbn_scope=scope, k=k, block_conv_type=block_conv_type, temporal_out=True, **kwargs)
     # yolo3.py:978-985
     if block_conv_type in ('3', '21'):
         assert k > 1, "k must be greater than 1 to use 3D or 2+1D convolutions"
