@@ -97,3 +97,24 @@ def test_temporal_out_inference_and_training(bct):
         gdev = net.collect_params()[k].grad().cpu().numpy().astype(np.float64)
         wr, _ = R.sgd_momentum(w0[k], gdev, np.zeros_like(gdev), 0.01, 0.9, 5e-4, 1.0 / (b * T_) / b)
         assert maxdiff(net.collect_params()[k].data().cpu().numpy(), wr) < 1e-6, k
+
+
+@pytest.mark.parametrize("flags", [
+    ["--window", "3,1", "--k_join_type", "max", "--k_join_pos", "late"],             # YOLOV3T k=3 (BASELINE configs[3])
+    ["--window", "5,1", "--temp", "--mult_out"],                                      # YOLOV3Temporal, per-frame outputs
+])
+def test_train_script_windows_end_to_end(tmp_path, monkeypatch, flags):
+    """train_yolov3.py on synthetic VID windows: loader (window batches, per-frame targets), network, loss logging,
+    validation with VOCMApMetric / VOCMApMetricTemporal, checkpoint."""
+    import glob
+    import os
+    import train_yolov3 as T
+    monkeypatch.chdir(tmp_path)
+    T.main(["--dataset", "vid", "--batch_size", "2", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "8",
+            "--save_prefix", "w", "--val_interval", "1", "--log_interval", "1"] + flags)
+    (log,) = glob.glob(os.path.join("models", "experiments", "w", "*_train.log"))
+    logs = open(log).read()
+    assert "Training cost" in logs and "Validation" in logs and "mAP" in logs, logs[-600:]
+    if "--mult_out" in flags:
+        assert "mAP t=4/5" in logs
+    assert glob.glob(os.path.join("models", "experiments", "w", "*.params"))

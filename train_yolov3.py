@@ -11,7 +11,8 @@ one RCCL all-reduce and `--syncbn` becomes a SyncBN collective.
 
 absl is not installed here: argparse re-creates the same flag surface (list flags take comma lists).
 `--features_dir` trains the neck/heads on cached backbone features (yolo3_no_backbone; features written by
-extract_base_features.py).  Variants outside the hot path (--temp, --motion_stream, --new_model, --hier, --rnn_pos,
+extract_base_features.py); `--window 5 --temp --mult_out` builds YOLOV3Temporal with per-frame outputs.  Variants
+outside the built scope (--temp without --mult_out, --motion_stream, --new_model, --hier, --rnn_pos,
 --corr_pos) are accepted and rejected with NotImplementedError like the reference's own guards.
 """
 import argparse
@@ -30,7 +31,7 @@ import torch
 from viddet_amd import dist as vdist
 from viddet_amd.data import (SyntheticDetection, YOLO3VideoTrainTransform, YOLO3VideoInferenceTransform, Loader,
                              FeatureDataset, YOLO3NBVideoTrainTransform, YOLO3NBVideoInferenceTransform)
-from viddet_amd.metrics import VOCMApMetric, LossMetric
+from viddet_amd.metrics import VOCMApMetric, VOCMApMetricTemporal, LossMetric
 from viddet_amd.model import yolo3_darknet53, yolo3_no_backbone
 from viddet_amd.schedule import LRScheduler, LRSequential
 
@@ -112,11 +113,15 @@ def get_dataset(dataset_name, dataset_val_name, save_prefix=""):
     """train_yolov3.py:167-231 — dataset readers are out of scope offline; synthetic frames stand in with the
     same class count and sample contract."""
     name = dataset_name[0] if len(dataset_name) == 1 else "comb"
-    train_ds = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples, seed=FLAGS.seed)
-    val_ds = SyntheticDetection(name, num_samples=max(8, FLAGS.synthetic_samples // 4), seed=FLAGS.seed + 1)
+    win = dict(window=int(FLAGS.window[0]), mult_out=FLAGS.mult_out)      # :196-206 VID windows / per-frame labels
+    train_ds = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples, seed=FLAGS.seed, **win)
+    val_ds = SyntheticDetection(name, num_samples=max(8, FLAGS.synthetic_samples // 4), seed=FLAGS.seed + 1, **win)
     if FLAGS.features_dir is not None:                 # :177-205 datasets built with features_dir
         train_ds, val_ds = FeatureDataset(train_ds, FLAGS.features_dir), FeatureDataset(val_ds, FLAGS.features_dir)
-    val_metric = VOCMApMetric(iou_thresh=0.5, class_names=val_ds.classes)
+    if FLAGS.mult_out:                                 # :207-210
+        val_metric = VOCMApMetricTemporal(t=int(FLAGS.window[0]), iou_thresh=0.5, class_names=val_ds.classes)
+    else:
+        val_metric = VOCMApMetric(iou_thresh=0.5, class_names=val_ds.classes)
     if FLAGS.num_samples < 0:
         FLAGS.num_samples = len(train_ds)
     return train_ds, val_ds, val_metric
@@ -175,7 +180,7 @@ def get_net(classes, rank_world):
     """train_yolov3.py:332-431 ('ours' definition, darknet53 only)."""
     if FLAGS.network != "darknet53":
         raise NotImplementedError("Backbone CNN model {} not implemented.".format(FLAGS.network))
-    for flag in ("temp", "mult_out", "new_model", "motion_stream", "rnn_pos", "corr_pos"):
+    for flag in ("new_model", "motion_stream", "rnn_pos", "corr_pos"):
         if getattr(FLAGS, flag):
             raise NotImplementedError("--%s selects a research variant outside the yolo3_darknet53 hot path" % flag)
     k = int(FLAGS.window[0])
@@ -191,7 +196,7 @@ def get_net(classes, rank_world):
                           norm_layer="syncbn" if FLAGS.syncbn and rank_world[1] > 1 else None,
                           norm_kwargs={"scope": FLAGS.syncbn_scope}, freeze_base=FLAGS.freeze_base,
                           k=k, k_join_type=FLAGS.k_join_type, k_join_pos=FLAGS.k_join_pos,
-                          block_conv_type=FLAGS.block_conv_type)
+                          block_conv_type=FLAGS.block_conv_type, temporal=FLAGS.temp, t_out=FLAGS.mult_out)   # :348-360
     net.initialize(init="he", seed=FLAGS.seed)
     start_epoch = FLAGS.start_epoch
     if FLAGS.resume.strip():

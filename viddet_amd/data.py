@@ -21,11 +21,16 @@ STD = np.array([0.229, 0.224, 0.225], np.float32)      # transforms.py:168
 class SyntheticDetection:
     """Deterministic synthetic dataset: uint8 frames with `max_gt` random boxes."""
 
-    def __init__(self, name="synthetic", num_samples=64, size=(480, 360), num_class=None, max_gt=8, seed=233):
+    def __init__(self, name="synthetic", num_samples=64, size=(480, 360), num_class=None, max_gt=8, seed=233,
+                 window=1, mult_out=False):
+        """window > 1: a sample is a window of `window` frames (k,h,w,3) as the VID dataset yields with
+        --window k (datasets/imgnetvid.py); its label is the centre frame's boxes, or with mult_out a list of
+        per-frame box arrays (--mult_out)."""
         self.name = name
         self.num_class = NUM_CLASSES.get(name, 20) if num_class is None else num_class
         self.classes = ["class%d" % i for i in range(self.num_class)]
         self._n, self._size, self._max_gt, self._seed = num_samples, size, max_gt, seed
+        self._window, self._mult_out = int(window), bool(mult_out)
 
     def __len__(self):
         return self._n
@@ -33,8 +38,7 @@ class SyntheticDetection:
     def sample_path(self, idx):
         return "synthetic/s%d_%06d.jpg" % (self._seed, idx)        # the seed keeps train / val file ids apart
 
-    def __getitem__(self, idx):
-        rng = np.random.default_rng(self._seed * 1000003 + idx)
+    def _frame(self, rng):
         w, h = self._size
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         n = int(rng.integers(1, self._max_gt + 1))
@@ -43,6 +47,16 @@ class SyntheticDetection:
         box = np.concatenate([np.clip(c - wh / 2, 0, (w - 1, h - 1)), np.clip(c + wh / 2, 0, (w - 1, h - 1))], axis=1)
         cls = rng.integers(0, self.num_class, (n, 1)).astype(np.float64)
         return img, np.concatenate([box, cls, np.zeros((n, 1))], axis=1)
+
+    def __getitem__(self, idx):
+        rng = np.random.default_rng(self._seed * 1000003 + idx)
+        if self._window <= 1:
+            return self._frame(rng)
+        frames = [self._frame(rng) for _ in range(self._window)]
+        imgs = np.stack([f[0] for f in frames])
+        if self._mult_out:
+            return imgs, [f[1] for f in frames]
+        return imgs, frames[self._window // 2][1]
 
 
 def _resize_nearest(img, w, h):
@@ -67,9 +81,14 @@ class YOLO3VideoInferenceTransform:
         self._w, self._h = width, height
 
     def __call__(self, img, label, idx=0):
-        h, w = img.shape[:2]
-        out = _to_tensor_normalize(_resize_nearest(img, self._w, self._h))
+        h, w = img.shape[-3], img.shape[-2]
+        if img.ndim == 4:                                  # (k,h,w,c) window -> (k,3,H,W)   transforms.py:322-343
+            out = np.stack([_to_tensor_normalize(_resize_nearest(f, self._w, self._h)) for f in img])
+        else:
+            out = _to_tensor_normalize(_resize_nearest(img, self._w, self._h))
         bb = tbbox.resize(label, (w, h), (self._w, self._h))
+        if isinstance(bb, (list, tuple)):                  # per-frame labels (--mult_out): (k, M, 6), -1 padded
+            return out, pad_stack([np.asarray(b, dtype=np.float32) for b in bb]), idx
         return out, bb.astype(np.float32), idx
 
 
@@ -81,13 +100,23 @@ class YOLO3VideoTrainTransform:
         self._rng = np.random.default_rng(0) if rng is None else rng
 
     def __call__(self, img, label):
-        h, w = img.shape[:2]
+        h, w = img.shape[-3], img.shape[-2]
         bb = tbbox.resize(label, (w, h), (self._w, self._h))
-        im = _resize_nearest(img, self._w, self._h)
+        frames = img if img.ndim == 4 else img[np.newaxis]             # (k,h,w,c); one flip decision per window
+        ims = [_resize_nearest(f, self._w, self._h) for f in frames]
         if self._rng.random() < 0.5:                                  # transforms.py:233-236
-            im = im[:, ::-1]
+            ims = [im[:, ::-1] for im in ims]
             bb = tbbox.flip(bb, (self._w, self._h), flip_x=True)
-        x = _to_tensor_normalize(im)
+        x = np.stack([_to_tensor_normalize(im) for im in ims])
+        if img.ndim != 4:
+            x = x[0]
+        if isinstance(bb, (list, tuple)):
+            # per-frame labels (--mult_out, transforms.py:252-294): targets of every frame stacked on a leading t axis,
+            # gt boxes (t, M, 4) padded with -1
+            tg = [prefetch_targets(self._h, self._w, b[np.newaxis, :, :4], b[np.newaxis, :, 4:5], self._c) for b in bb]
+            cols = [np.concatenate([t[i] for t in tg], axis=0) for i in range(5)]
+            gt = pad_stack([np.asarray(b[:, :4], dtype=np.float32) for b in bb])
+            return (x,) + tuple(cols) + (gt,)
         gt = bb[np.newaxis, :, :4]
         ids = bb[np.newaxis, :, 4:5]
         obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c)
@@ -152,10 +181,12 @@ class YOLO3NBVideoInferenceTransform:
 
 
 def pad_stack(arrs, pad_val=-1.0):
-    m = max(a.shape[0] for a in arrs)
-    out = np.full((len(arrs), m) + arrs[0].shape[1:], pad_val, dtype=np.float32)
+    """Stack arrays whose leading dims are ragged (Pad(pad_val=-1) batchify, axis 0 for (M,.) labels and axis 1 for
+    the (t,M,.) per-frame labels of --mult_out, train_yolov3.py:253-256,273-276)."""
+    shape = tuple(max(a.shape[d] for a in arrs) for d in range(arrs[0].ndim))
+    out = np.full((len(arrs),) + shape, pad_val, dtype=np.float32)
     for i, a in enumerate(arrs):
-        out[i, :a.shape[0]] = a
+        out[(i,) + tuple(slice(0, n) for n in a.shape)] = a
     return out
 
 
