@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = bf16 storage/MFMA inference (detect mode only)")
     ap.add_argument("--graphs", action="store_true", help="replay the inference program as a captured HIP graph")
+    ap.add_argument("--window", type=int, default=1, help="frames per sample (k); 3 with the join flags = BASELINE configs[3]")
+    ap.add_argument("--k-join-type", default="max", choices=["max", "mean", "cat"])
+    ap.add_argument("--k-join-pos", default="late", choices=["early", "late"])
+    ap.add_argument("--block-conv-type", default="2", choices=["2", "3", "21"])
     ap.add_argument("--detail", default=None, help="write a per-launch conv table (JSON) to this path")
     ap.add_argument("--obj-bias", type=float, default=None,
                     help="objectness bias of the random-init heads (default: calibrated so ~2%% of score rows pass)")
@@ -87,8 +91,11 @@ def main():
     S = a.size or (416 if train else 608)
     C = a.classes
     classes = ["c%d" % i for i in range(C)]
+    K = max(1, a.window)
     net = yolo3_darknet53(classes, norm_layer="syncbn" if a.syncbn else None,
-                          norm_kwargs={"scope": a.syncbn} if a.syncbn else None)
+                          norm_kwargs={"scope": a.syncbn} if a.syncbn else None,
+                          **(dict(k=K, k_join_type=a.k_join_type, k_join_pos=a.k_join_pos,
+                                  block_conv_type=a.block_conv_type) if K > 1 else {}))
     # He init keeps synthetic activations O(1); objectness bias negative so only a few % of the C*P score rows
     # pass valid_thresh, as with a trained net.  Same seed on every rank => identical replicas.
     net.initialize(init="he", seed=233, obj_bias=-4.0)
@@ -96,7 +103,10 @@ def main():
         if train:
             raise SystemExit("--dtype bf16 is an inference path (training is fp32 like the reference)")
         net.set_precision("bf16")
-    x_np, gt_np, ids_np = synthetic_batch(B, S, C, 233 + rank)
+    x_np, gt_np, ids_np = synthetic_batch(B * K, S, C, 233 + rank)
+    if K > 1:                      # B windows of K frames; the labels are the centre frame's (one gt set per window)
+        x_np = x_np.reshape(B, K, 3, S, S)
+        gt_np, ids_np = gt_np.reshape(B, K, -1, 4)[:, K // 2], ids_np.reshape(B, K, -1, 1)[:, K // 2]
     x = torch.from_numpy(x_np).cuda()
     if train:
         tg = prefetch_targets(S, S, gt_np, ids_np, C)
@@ -155,7 +165,7 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    fps = world * B * a.steps / dt
+    fps = world * B * K * a.steps / dt            # frames (a window of k frames counts k; windows/s is in config)
 
     # ---- phase split (one extra step with device syncs between phases; not part of the timed region)
     phases = None
@@ -261,17 +271,23 @@ def main():
     if world > 1 or force_dist:
         torch.distributed.barrier()
     if rank == 0:
-        gflop = 197.3 if (train and S == 416 and C == 80) else None
+        gflop = 197.3 if (train and S == 416 and C == 80 and K == 1) else None
         out = {
             "metric": ("frames/sec (%dx%d) yolo3_darknet53 fwd+bwd" % (S, S)) if train else
                       ("detect fps (%dx%d) yolo3_darknet53 fwd+decode+NMS" % (S, S)),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
+            "config": {"workload": (("temporal-YOLO (k=%d frame windows) training, %d windows/GPU, %dx%d, fp32, fwd+bwd+"
+                                     "SGD-momentum (BASELINE configs[3] family)" % (K, B, S, S)) if (train and K > 1) else
+                                    "yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
                                     "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),
                        "classes": C, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "window": (None if K == 1 else {"k": K, "k_join_type": a.k_join_type, "k_join_pos": a.k_join_pos,
+                                                       "block_conv_type": a.block_conv_type,
+                                                       "windows_per_s": round(fps / K, 2),
+                                                       "note": "BASELINE configs[3] family: batch = windows per GPU"}),
                        "syncbn": a.syncbn, "score_filter": (None if train else pass_info),
                        "hip_graph": bool(a.graphs) and not train,
                        "fp32_math": (None if a.dtype == "bf16" else
