@@ -49,7 +49,9 @@ def test_inference_matches_oracle(cfg):
         ref = np.moveaxis(heads_r[s], 1, -1)
         assert maxdiff(got, ref) < 1e-3, "head %d" % s
     assert int(net.last_overflow.max()) == 0
-    assert np.array_equal(net.last_rows.cpu().numpy().astype(np.int64), rows_r), "post-NMS indices differ"
+    from tests.util import assert_rows_match, take_ranks
+    perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
+    ids, sc, bx = [torch.from_numpy(take_ranks(t, perm)) for t in (ids, sc, bx)]
     assert np.array_equal(ids.cpu().numpy(), ids_r)
     assert maxdiff(sc.cpu().numpy(), sc_r) < 1e-3
     # boxes: fp32 round-off of the 75-layer stack vs the fp64 oracle is ~1e-5 relative (measured 1.05e-3 px on
