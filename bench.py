@@ -79,10 +79,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    # developer rehearsal of the world>1 logic on a ONE-GPU box: every rank on cuda:0, gloo instead of RCCL (RCCL
+    # refuses two ranks on one device).  Not a measurement mode.
+    rehearse = os.environ.get("VD_REHEARSE_SHARED_GPU", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     force_dist = os.environ.get("VD_FORCE_DIST", "0") == "1"      # exercise the RCCL path with a single rank
     if world > 1 or force_dist:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     from viddet_amd.model import yolo3_darknet53
     from viddet_amd.targets import synthetic_batch, prefetch_targets
 

@@ -143,3 +143,15 @@ def test_reset_class_reuses_rows():
     ids, sc, bx = net(x)
     torch.cuda.synchronize()
     assert ids.shape == (1, 100, 1)
+
+
+def test_data_parallel_two_ranks_equal_one_process():
+    """tools/dp_equivalence.py: two ranks (gloo on the one GPU; RCCL needs one device per rank) with SyncBN('all'),
+    bucketed gradient all-reduce and the global-batch rescale reproduce the single-process step on the whole batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
