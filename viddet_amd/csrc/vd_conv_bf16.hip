@@ -16,6 +16,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROW_B = 144;              // LDS row: 128 B of K + 16 B pad
 constexpr int KCH = 64;                 // bf16 channels per K-step
@@ -91,14 +92,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    f32x4 ra[AP], rb[BP];
+    // PD register sets of gathered tiles + a branch-free steady-state loop: see k_conv_igemm (vd_conv.hip)
+    constexpr int PD = (WM * WN == 4 && TM * TN == 4) ? 2 : 3;
+    f32x4 ra[PD][AP], rb[PD][BP];
     int t_tap = 0, c0 = 0;
 
     auto tap_off = [&](int t) -> int64_t {
         return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
     };
     int64_t tap_soff = tap_off(0);
-    auto gload = [&]() {
+    auto gload = [&](f32x4 (&ra)[AP], f32x4 (&rb)[BP]) {
         const int64_t soff = tap_soff + c0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             if (t_tap < p.T) tap_soff = tap_off(t_tap);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
         unsigned char* a = As + buf * BM * ROW_B;
         unsigned char* b = Bs + buf * BN * ROW_B;
 #pragma unroll
@@ -146,42 +149,106 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     };
 
     const int nks = p.T * (p.Ci / KCH);
-    gload();
-    lstore(0);
+    gload(ra[0], rb[0]);
+    lstore(0, ra[0], rb[0]);
     __syncthreads();
-    const int probe = (p.flags >> 8) & 7;      // timing probes (VD_IGEMM_PROBE), see vd_conv.hip
-    for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
-        const bool more = (ks + 1 < nks);
-        if (more && !(probe & 1)) gload();
-        compute(cur);
-        if (more && !(probe & 2)) lstore(cur ^ 1);
-        if (!(probe & 4)) __syncthreads();
+    constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;
+#pragma unroll
+    for (int d = 1; d < PD; ++d)
+        if (d < nks) gload(ra[d], rb[d]);
+    int ks = 0;
+    if (nks >= PD) {
+        for (; ks + UN + PD <= nks; ks += UN) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                gload(ra[u % PD], rb[u % PD]);
+                compute(u & 1);
+                lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
+    }
+    for (; ks < nks; ks += UN) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ks + u < nks) {
+                if (ks + u + PD < nks) gload(ra[u % PD], rb[u % PD]);
+                compute(u & 1);
+                if (ks + u + 1 < nks) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
     }
 
-    // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs)
+    // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs).  Per wave, one 32x32
+    // accumulator tile at a time is transposed through a private LDS patch so that each lane owns 4 consecutive
+    // columns of 4 rows: scale/shift/LeakyReLU/residual on 4-vectors and 8-byte (bf16 x4) or 16-byte (fp32 heads)
+    // stores instead of 2 bytes per lane.
     const __bf16* res = reinterpret_cast<const __bf16*>(p.residual);
+    constexpr int SLD = 36;
+    float* stg = reinterpret_cast<float*>(smem_b) + wave * (32 * SLD);
+    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
+                        (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0)));
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + (lane & 31);
-        const bool cok = col < p.Co;
-        float sc = 1.f, sh = 0.f;
-        if ((p.flags & VD_EPI_AFFINE) && cok) {
-            if (p.scale) sc = p.scale[col];
-            if (p.shift) sh = p.shift[col];
+        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
+        const int nvalid = p.Co - col;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.flags & VD_EPI_AFFINE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nvalid) {
+                    if (p.scale) sc[e] = p.scale[col + e];
+                    if (p.shift) sh[e] = p.shift[col + e];
+                }
         }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (!cok || m >= M) continue;
-                float v = acc[mi][ni][r];
-                if (p.flags & VD_EPI_AFFINE) v = v * sc + sh;
-                if (p.flags & VD_EPI_LEAKY) v = v > 0.f ? v : v * p.slope;
-                if (p.flags & VD_EPI_RESIDUAL) v += (float)res[m * p.ldr + col];
-                if (OUT_F32) p.out[m * p.ldo + col] = v;
-                else reinterpret_cast<__bf16*>(p.out)[m * p.ldo + col] = (__bf16)v;
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = erow + 8 * i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SLD + ec4);
+                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
+                if (nvalid <= 0 || m >= M) continue;
+                if (p.flags & VD_EPI_AFFINE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+                }
+                if (p.flags & VD_EPI_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                }
+                if (nvalid >= 4 && vec_ok) {
+                    if (p.flags & VD_EPI_RESIDUAL) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + m * p.ldr + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + col) = v;
+                    else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + m * p.ldo + col) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < nvalid) {
+                            float t = v[e];
+                            if (p.flags & VD_EPI_RESIDUAL) t += (float)res[m * p.ldr + col + e];
+                            if (OUT_F32) p.out[m * p.ldo + col + e] = t;
+                            else reinterpret_cast<__bf16*>(p.out)[m * p.ldo + col + e] = (__bf16)t;
+                        }
+                }
             }
         }
     }
