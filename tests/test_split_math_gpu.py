@@ -20,7 +20,7 @@ SHAPES = [  # n, ci, h, w, co, k, stride, pad
 ]
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])      # 5..8: the same tiles on the 16x16x32 MFMA shape
 @pytest.mark.parametrize("shape", SHAPES)
 def test_split_fwd_every_tile(tile, shape):
     from viddet_amd import ops
@@ -138,7 +138,7 @@ def test_split_fused_bn_statistics():
     rng, x, wt = _mk(n, ci, h, w, co, k, 123)
     ref = R.conv2d(x, wt, 1, 1)
     M = n * h * w
-    for tile in (1, 2, 3, 4):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
         d = L.ConvDesc()
         xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
         out = torch.empty(n, h, w, co, device="cuda")
@@ -152,7 +152,7 @@ def test_split_fused_bn_statistics():
         L.check(lib.vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
         mt = lib.vd_conv_igemm_mtiles(C.byref(d))
         torch.cuda.synchronize()
-        assert mt == -(-M // (256 if tile in (1, 3) else 128))
+        assert mt == -(-M // (256 if tile in (1, 3, 5, 7) else 128))
         s1 = part[:mt, :co].double().sum(0).cpu().numpy()
         s2 = part[:mt, co:].double().sum(0).cpu().numpy()
         assert np.abs(s1 - ref.sum((0, 2, 3))).max() < 2e-3

@@ -127,10 +127,10 @@ def _tile_candidates(d, math):
         else:
             cands += [(0, t) for t in (1, 2, 3, 4, 5)]
     if math in ("split", "auto"):
-        if d.Co <= 64:
-            cands += [(L.MATH_SPLIT, 3), (L.MATH_SPLIT, 4)]
+        if d.Co <= 64:           # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
+            cands += [(L.MATH_SPLIT, t) for t in (3, 4, 7, 8)]
         else:
-            cands += [(L.MATH_SPLIT, t) for t in (1, 2, 3, 4)]
+            cands += [(L.MATH_SPLIT, t) for t in (1, 2, 3, 4, 5, 6, 7, 8)]
     return cands
 
 
