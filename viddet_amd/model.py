@@ -477,6 +477,7 @@ class YOLOV3(object):
         self.fuse_bn_stats = _os.environ.get('VD_FUSE_STATS', '1') != '0'  # BN statistics in the conv epilogue
         self.precision = 'fp32'        # inference precision: 'fp32' | 'bf16' (set_precision)
         self.bucketed_allreduce = _os.environ.get('VD_BUCKETED', '1') != '0'
+        self.alias_skip_grad = _os.environ.get('VD_ALIAS_SKIP', '1') != '0'    # skip gradients by alias, not by copy
         self.bucket_elems = 16 << 20   # 64 MB of fp32 gradients per all-reduce
         self._pending_reduces = []
         self._reduced_from = 1 << 62
@@ -1132,9 +1133,23 @@ class YOLOV3(object):
         written = set(self.head_names)     # gradients already produced (the loss kernel wrote d:head*)
         dgrad_packs = []                   # (node, plan, packed weight buffer) re-packed when weights change
 
-        def grad_into(name, numel):
+        # d:x of a residual block input x is  dy_block (skip)  +  dgrad(first conv of the block).  The skip term is not
+        # copied: it stays an alias of the block's dy until the dgrad, which reads it as its epilogue residual and
+        # writes d:x out of place (saves a read + write of every block output per step).
+        alias = {}
+
+        def materialize(name):
+            if name in alias:
+                src = alias.pop(name)
+                seg.add('vd_bn_apply_leaky', src.data_ptr(), self._ones(src.shape[-1]).data_ptr(),
+                        self._zeros(src.shape[-1]).data_ptr(), None, bufs['d:' + name].data_ptr(),
+                        src.numel() // src.shape[-1], src.shape[-1], 1.0)
+
+        def grad_into(name, numel, can_alias=False):
             """Return (dst_ptr, accumulate?) for a producer of d:name."""
             if name in written:
+                if not can_alias:
+                    materialize(name)
                 return bufs['d:' + name], True
             written.add(name)
             return bufs['d:' + name], False
@@ -1173,6 +1188,7 @@ class YOLOV3(object):
             M = B * n.fr * Ho * Wo
             dy = bufs['d:' + n.dst]
             assert n.dst in written, n.name
+            materialize(n.dst)
             if n.head:
                 dz = dy
                 # bias gradient = per-channel sum of dz (reuses the BN column-sum kernels)
@@ -1184,9 +1200,9 @@ class YOLOV3(object):
                     if acc:
                         seg.add('vd_add', dres.data_ptr(), dy.data_ptr(), dres.data_ptr(), dy.numel())
                     else:
-                        # first producer of the skip gradient: it IS dy (copy = add with a zero-free form)
-                        seg.add('vd_bn_apply_leaky', dy.data_ptr(), self._ones(n.cout).data_ptr(),
-                                self._zeros(n.cout).data_ptr(), None, dres.data_ptr(), M, n.cout, 1.0)
+                        alias[n.residual] = dy     # first producer of the skip gradient: it IS dy (no copy, see alias)
+                        if not self.alias_skip_grad:
+                            materialize(n.residual)
                 z = bufs['z:' + n.dst]
                 slot = n_dz[0] % 2
                 n_dz[0] += 1
@@ -1241,7 +1257,8 @@ class YOLOV3(object):
             if n.stem or n.src in self.input_tensors:     # no gradient flows into the network inputs
                 continue
             # data gradient into d:src
-            dsrc, acc = grad_into(n.src, 0)
+            dsrc, acc = grad_into(n.src, 0, can_alias=True)
+            res_src = alias.pop(n.src) if n.src in alias else dsrc      # the skip gradient, still living in the block's dy
             for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, n.kd, n.pad_d):
                 assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
                 wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
@@ -1257,7 +1274,7 @@ class YOLOV3(object):
                 d.ldo = d.ldr = n.cin
                 d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
                 if acc:
-                    d.residual = dsrc.data_ptr()
+                    d.residual = res_src.data_ptr()
                 seg.hold(d, wpk)
                 nplans = n.stride * n.stride
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
