@@ -86,6 +86,19 @@ typedef struct {
      * stats_part[tile_m][0..Co) = sum, [Co..2Co) = sum of squares; vd_conv_igemm_mtiles() rows;
      * finish with vd_bn_sum_partials().  NULL = off. */
     float*  stats_part;
+    /* fused BatchNorm BACKWARD reductions (training; this launch is the data-gradient conv that writes the final
+     * gradient dy of a BatchNorm+LeakyReLU output, direct geometry: out_stride 1, Ho==Hg, Wo==Wg).  With
+     * g = dy * leaky'(z*bs_scale+bs_shift) and xhat = (z - bs_mean)*bs_invstd, the epilogue adds the per-M-tile
+     * partial sums  bs_part[tile_m][0..Co) = sum g,  [Co..2Co) = sum g*xhat  (rows as vd_conv_igemm_mtiles());
+     * bs_z is that layer's pre-BN conv output, laid out like `out` (pitch ldo).  Finish with
+     * vd_bn_sum_partials(); replaces vd_bn_bwd_reduce.  bs_part NULL = off. */
+    const float* bs_z;
+    const float* bs_scale;
+    const float* bs_shift;
+    const float* bs_mean;
+    const float* bs_invstd;
+    float*  bs_part;
+    float   bs_slope;
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);

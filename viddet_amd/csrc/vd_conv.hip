@@ -98,8 +98,11 @@ struct RowInfo {
 // M16 (split math only): v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - the same cycles per FLOP, but the chip holds a
 // higher clock on it under load (MI355X_MICROARCH.md, DVFS item 7).  A 32x32 accumulator region is then four 16x16
 // tiles kept in one f32x16 as [4*(2*sm+sn) + r]: rows 16*sm + 4*(lane>>4) + r, column 16*sn + (lane&15).
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
+// BS: instantiation with the fused BatchNorm-backward reductions in the epilogue (their accumulators would cost the
+// other instantiations registers, and the 8-wave fp32-MFMA tiles sit at the 128-VGPR occupancy edge)
+// (second launch bound: the 8-wave fp32-MFMA tiles run two workgroups per CU = 4 waves per SIMD = 128 VGPRs)
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false>
+__global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     static_assert(!M16 || SP, "the 16x16x32 shape exists for the bf16 operands of the split arithmetic");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
@@ -405,6 +408,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                          p.Wo == p.Wg);
     float* stg = smem + wave * (32 * LDS_LD);
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    const bool bstat = BS && p.bs_part != nullptr;      // fused BatchNorm backward reductions (see viddet_hip.h)
+    float bs1[TN][4], bs2[TN][4];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs1[ni][e] = bs2[ni][e] = 0.f;
     // float4 path: rows 16-B aligned (wave-uniform; every tensor of the model qualifies, odd pitches fall back)
     const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
                         (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 16 == 0)));
@@ -420,6 +429,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                     if (p.scale) sc[e] = p.scale[col + e];
                     if (p.shift) sh[e] = p.shift[col + e];
                 }
+        }
+        float qsc[4], qsh[4], qmu[4], qis[4];             // BatchNorm constants of the layer whose dy this is
+        if (bstat) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = e < nvalid;
+                qsc[e] = ok ? p.bs_scale[col + e] : 0.f;
+                qsh[e] = ok ? p.bs_shift[col + e] : 0.f;
+                qmu[e] = ok ? p.bs_mean[col + e] : 0.f;
+                qis[e] = ok ? p.bs_invstd[col + e] : 0.f;
+            }
         }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -458,6 +478,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                 if (nvalid >= 4 && vec_ok) {
                     if (p.flags & VD_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + opix * p.ldr + col);
                     *reinterpret_cast<f32x4*>(dst) = v;
+                    if (bstat) {
+                        const f32x4 z = *reinterpret_cast<const f32x4*>(p.bs_z + opix * p.ldo + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u = z[e] * qsc[e] + qsh[e];
+                            const float g = u > 0.f ? v[e] : v[e] * p.bs_slope;
+                            bs1[ni][e] += g;
+                            bs2[ni][e] += g * (z[e] - qmu[e]) * qis[e];
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -465,8 +495,51 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const vd_conv_desc 
                             float t = v[e];
                             if (p.flags & VD_EPI_RESIDUAL) t += p.residual[opix * p.ldr + col + e];
                             dst[e] = t;
+                            if (bstat) {
+                                const float z = p.bs_z[opix * p.ldo + col + e];
+                                const float u = z * qsc[e] + qsh[e];
+                                const float g = u > 0.f ? t : t * p.bs_slope;
+                                bs1[ni][e] += g;
+                                bs2[ni][e] += g * (z - qmu[e]) * qis[e];
+                            }
                         }
                 }
+            }
+        }
+    }
+
+    // ---- fused BatchNorm backward reductions: a lane holds 4 columns x (4 rows x TM tiles); fold the 8 row groups of
+    // the wave (lane bits 3..5), then the WM waves that share the columns, one writer per (tile_m, column)
+    if (bstat) {
+        __syncthreads();        // every wave is done with its staging patch
+        float* red = smem;      // [WM][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = bs1[ni][e], b = bs2[ni][e];
+                a += __shfl_xor(a, 8);  b += __shfl_xor(b, 8);
+                a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                if (lane < 8) {
+                    const int c = wn * TN * 32 + ni * 32 + ec4 + e;
+                    red[(wm * BN + c) * 2 + 0] = a;
+                    red[(wm * BN + c) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            const int colc = tile_n * BN + c;
+            if (colc < p.Co) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    a += red[(w * BN + c) * 2 + 0];
+                    b += red[(w * BN + c) * 2 + 1];
+                }
+                float* dstp = p.bs_part + (int64_t)tile_m * 2 * p.Co;
+                dstp[colc] = a;
+                dstp[p.Co + colc] = b;
             }
         }
     }
@@ -552,13 +625,23 @@ const float* zero_page() {
     return zp;
 }
 
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS>
+int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s);
+
 template <int WM, int WN, int TM, int TN, bool XF, bool SP = false, bool M16 = false>
 int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
+    // the in-load transform (XF) and the backward reductions never meet: one is a forward feature, one a dgrad one
+    if (!XF && d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true>(d, s);
+    return launch_igemm_bs<WM, WN, TM, TN, XF, SP, M16, false>(d, s);
+}
+
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS>
+int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds = SP ? 2 * (BM + BN) * SP_ROWB : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= WM * WN * 32 * LDS_LD * 4, "LDS budget (operand stages; epilogue patches)");
     static bool attr_done = false;
-    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16>;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
@@ -1099,6 +1182,9 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
     VD_REQUIRE(!d->stats_part || (d->flags & 7) == 0, "vd_conv_igemm: fused BN statistics need a raw (epilogue-free) output");
+    VD_REQUIRE(!d->bs_part || (!d->stats_part && !d->in_scale && d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd &&
+                               d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg),
+               "vd_conv_igemm: fused BN backward reductions need direct output geometry and all five bs_* inputs");
     hipStream_t s = (hipStream_t)stream;
     if (d->in_scale) dispatch_igemm<true>(*d, s);
     else dispatch_igemm<false>(*d, s);

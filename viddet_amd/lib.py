@@ -29,6 +29,8 @@ class ConvDesc(C.Structure):
         ("ldo", C.c_int32), ("ldr", C.c_int32), ("flags", C.c_int32), ("slope", C.c_float),
         ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float), ("tile", C.c_int32),
         ("stats_part", _fp),
+        ("bs_z", _fp), ("bs_scale", _fp), ("bs_shift", _fp), ("bs_mean", _fp), ("bs_invstd", _fp), ("bs_part", _fp),
+        ("bs_slope", C.c_float),
     ]
 
 

@@ -478,6 +478,7 @@ class YOLOV3(object):
         self.precision = 'fp32'        # inference precision: 'fp32' | 'bf16' (set_precision)
         self.bucketed_allreduce = _os.environ.get('VD_BUCKETED', '1') != '0'
         self.alias_skip_grad = _os.environ.get('VD_ALIAS_SKIP', '1') != '0'    # skip gradients by alias, not by copy
+        self.fuse_bn_bwd = _os.environ.get('VD_FUSE_BWD', '1') != '0'          # BN backward reductions in the dgrad epilogue
         self.bucket_elems = 16 << 20   # 64 MB of fp32 gradients per all-reduce
         self._pending_reduces = []
         self._reduced_from = 1 << 62
@@ -1137,6 +1138,17 @@ class YOLOV3(object):
         # copied: it stays an alias of the block's dy until the dgrad, which reads it as its epilogue residual and
         # writes d:x out of place (saves a read + write of every block output per step).
         alias = {}
+        # BatchNorm backward reductions (sum g, sum g*xhat over dy and z) ride in the epilogue of the data-gradient conv
+        # that writes the FINAL dy of a BatchNorm output - the earliest forward consumer, processed last here - when
+        # that conv is a single stride-1 launch; the standalone two-tensor reduction pass is then skipped.
+        producers = {m.dst: m for m in self.conv_nodes if m.bn}
+        consumers = {}
+        for m in self.nodes:
+            srcs = [m.src, m.residual] if isinstance(m, ConvNode) else ([m.up, m.route] if isinstance(m, UpcatNode) else [m.src])
+            for t in srcs:
+                if t:
+                    consumers.setdefault(t, []).append(m)
+        fused_bwd = set()
 
         def materialize(name):
             if name in alias:
@@ -1207,9 +1219,10 @@ class YOLOV3(object):
                 slot = n_dz[0] % 2
                 n_dz[0] += 1
                 dz = dz_bufs[slot][:M * n.cout].view(B * n.fr, Ho, Wo, n.cout)
-                seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
-                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
-                        ws.data_ptr(), ws_bytes)
+                if n.name not in fused_bwd:
+                    seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                            n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
+                            ws.data_ptr(), ws_bytes)
                 seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
                 count = float(M)
                 if self._syncbn(n):
@@ -1259,7 +1272,11 @@ class YOLOV3(object):
             # data gradient into d:src
             dsrc, acc = grad_into(n.src, 0, can_alias=True)
             res_src = alias.pop(n.src) if n.src in alias else dsrc      # the skip gradient, still living in the block's dy
-            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, n.kd, n.pad_d):
+            plans = dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, n.kd, n.pad_d)
+            pm = producers.get(n.src)
+            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and len(plans) == 1 and n.stride == 1 and
+                            consumers[n.src][0] is n and pm.fr == n.fr) else None
+            for plan in plans:
                 assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
                 wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
                 dgrad_packs.append((n, plan, wpk))
@@ -1277,10 +1294,22 @@ class YOLOV3(object):
                     d.residual = res_src.data_ptr()
                 seg.hold(d, wpk)
                 nplans = n.stride * n.stride
+                if fuse_m is not None:
+                    d.bs_z = bufs['z:' + fuse_m.dst].data_ptr()
+                    d.bs_scale, d.bs_shift = fuse_m.b_scale.data_ptr(), fuse_m.b_shift.data_ptr()
+                    d.bs_mean, d.bs_invstd = fuse_m.b_mean.data_ptr(), fuse_m.b_invstd.data_ptr()
+                    d.bs_part, d.bs_slope = stats_ws.data_ptr(), LEAKY_SLOPE
+                    autotune_desc(d)                               # fixes the tile, hence the number of M tiles
+                    mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
+                    assert mt * 2 * fuse_m.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
                     bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans))
+                if fuse_m is not None:
+                    seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
+                            ws.data_ptr(), ws_bytes)
+                    fused_bwd.add(fuse_m.name)
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
         seg.hold(ws_w, side, stats_ws)
