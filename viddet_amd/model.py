@@ -482,6 +482,7 @@ class YOLOV3(object):
         self.bucket_elems = 16 << 20   # 64 MB of fp32 gradients per all-reduce
         self._pending_reduces = []
         self._reduced_from = 1 << 62
+        self._bucket_group = None      # second communicator for the gradient buckets when SyncBN collectives exist
         self._build(len(self._classes))
 
     # ------------------------------------------------------------------ construction
@@ -1031,6 +1032,12 @@ class YOLOV3(object):
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.process_group)
+            # With SyncBN the statistics all-reduces sit on the critical path of backward; on one communicator they
+            # would queue behind a 64 MB gradient bucket in flight (one RCCL stream per communicator).  The buckets get
+            # their own communicator (new_group is collective: every rank builds its training plan at the same point).
+            if (world > 1 and self.syncbn_scope and self.bucketed_allreduce and self._bucket_group is None
+                    and self.process_group is None):
+                self._bucket_group = torch.distributed.new_group()
 
         # partial-sum table of the fused BN statistics: rows = M tiles (>= 64 rows each), 2*Cout floats per row
         smax = 16
@@ -1436,7 +1443,8 @@ class YOLOV3(object):
                 return
             st = side if side is not None else torch.cuda.current_stream()
             with torch.cuda.stream(st):
-                h = torch.distributed.all_reduce(self.grads[lo:hi], group=self.process_group, async_op=True)
+                h = torch.distributed.all_reduce(self.grads[lo:hi], group=self._bucket_group or self.process_group,
+                                                 async_op=True)
             self._pending_reduces.append(h)
             self._reduced_from = min(self._reduced_from, lo)
         return f
