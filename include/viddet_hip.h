@@ -141,6 +141,20 @@ typedef struct {
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d);
 int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stream);
 
+/* Direct stem convolution (3x3, 3 -> 32 channels, stride 1, pad 1; three_darknet.py:163-164) straight from the NCHW
+ * fp32 frame batch (transforms.py:239-245): no im2col round trip.  wp is the fwd-packed stem weight [32][32]
+ * (k = (ky*3+kx)*3 + c, k >= 27 zero).  out: NHWC [N,H,W,ldo >= 32] (32 channels written per pixel; a wider pitch
+ * leaves the pad channels alone) fp32, or bf16 when out_bf16; flags = VD_EPI_AFFINE /
+ * VD_EPI_LEAKY (BN-eval fold + LeakyReLU); stats_part (flags 0, fp32 out): per-block BatchNorm partial sums
+ * [vd_stem_conv_blocks()][2*32], finish with vd_bn_sum_partials(). */
+int vd_stem_conv_blocks(int N, int H, int W);
+int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N, int H, int W, const float* scale,
+                 const float* shift, float slope, int flags, int out_bf16, float* stats_part, void* stream);
+/* Weight gradient of the stem from the same NCHW batch and the gradient dz [N*H*W][ldd >= 32] of its output:
+ * dwp [32][32] in the fwd-packed layout (columns >= 27 come out zero). */
+int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W);
+int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int N, int H, int W, void* ws,
+                  int64_t ws_bytes, void* stream);
 /* Stem conv 3->32 3x3 s1 p1 (three_darknet.py:163-164): Ci=3 is too thin for the GEMM path, so
  * the stem is lowered to an explicit 32-wide im2col ( col[n,y,x,(ky*3+kx)*3+c], entries 27..31
  * zero ) followed by vd_conv_igemm / vd_conv_wgrad with T=1, Ci=32.  `in` is [N,H,W,3] (nchw=0)

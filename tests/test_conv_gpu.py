@@ -259,3 +259,56 @@ def test_bn_sum_partials_tall_table():
     L.check(L.load().vd_bn_sum_partials(pd.data_ptr(), nblk, c, sums.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "sum")
     torch.cuda.synchronize()
     assert maxdiff(sums.cpu().numpy(), part.astype(np.float64).sum(axis=0)) < 1e-9
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16), (3, 13, 21), (1, 64, 64), (5, 7, 9)])
+def test_stem_direct_conv_forward_wgrad_stats(shape):
+    """vd_stem_conv / vd_stem_wgrad (3x3, 3 -> 32 from the NCHW batch, no im2col) vs the oracle conv; the fused
+    per-block BatchNorm partial sums; bf16 output at its rounding."""
+    import ctypes as C
+    from viddet_amd import ops, lib as L
+    n, h, w = shape
+    rng, x, wt = _mk(n, 3, h, w, 32, 3, 80 + n)
+    ref = R.conv2d(x, wt, 1, 1)
+    xd = dev(x)                                                   # (n,3,h,w) NCHW
+    # k index of the packed stem weight: (ky*3+kx)*3 + c
+    wk = np.zeros((32, 32), np.float32)
+    for ky in range(3):
+        for kx in range(3):
+            for c in range(3):
+                wk[:, (ky * 3 + kx) * 3 + c] = wt[:, c, ky, kx]
+    wp = dev(wk)
+    out = torch.full((n, h, w, 32), 7.0, device="cuda")
+    nb = L.load().vd_stem_conv_blocks(n, h, w)
+    part = torch.full((nb, 64), 9.0, device="cuda")
+    ops.stem_conv(xd, wp, out, stats_part=part)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out), ref) < TOL
+    assert maxdiff(part[:, :32].double().sum(0).cpu().numpy(), ref.sum((0, 2, 3))) < 1e-3
+    assert maxdiff(part[:, 32:].double().sum(0).cpu().numpy(), (ref ** 2).sum((0, 2, 3))) < 1e-3 * max(1.0, float((ref ** 2).sum((0, 2, 3)).max()) / 100)
+    # BN-eval fold + LeakyReLU epilogue, fp32 and bf16 outputs
+    sc, sh = rng.uniform(0.5, 1.5, 32), rng.standard_normal(32)
+    u = ref * sc[None, :, None, None] + sh[None, :, None, None]
+    refa = np.where(u > 0, u, 0.1 * u)
+    ops.stem_conv(xd, wp, out, scale=dev(sc), shift=dev(sh), leaky=True)
+    ob = torch.zeros(n, h, w, 64, device="cuda", dtype=torch.bfloat16)       # pitch 64: pad channels stay untouched
+    ops.stem_conv(xd, wp, ob, scale=dev(sc), shift=dev(sh), leaky=True)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out), refa) < TOL
+    assert maxdiff(dev_nhwc_to_nchw(ob.float(), 32), refa) < 2.0 ** -8 * max(1.0, float(np.abs(refa).max()))
+    assert float(ob[..., 32:].float().abs().max()) == 0.0
+    # weight gradient
+    dy = rng.standard_normal((n, 32, h, w))
+    _, dw_ref = R.conv2d_backward(x, wt, dy, 1, 1)
+    dwp = torch.full((32, 32), 5.0, device="cuda")
+    ws = torch.empty(max(16, L.load().vd_stem_wgrad_ws_bytes(n, h, w)), dtype=torch.uint8, device="cuda")
+    ops.stem_wgrad(xd, nchw_to_dev_nhwc(dy), dwp, ws)
+    torch.cuda.synchronize()
+    got = dwp.cpu().numpy()
+    dwk = np.zeros((32, 32))
+    for ky in range(3):
+        for kx in range(3):
+            for c in range(3):
+                dwk[:, (ky * 3 + kx) * 3 + c] = dw_ref[:, c, ky, kx]
+    assert maxdiff(got, dwk) < TOL * np.sqrt(n * h * w)
+    assert float(np.abs(got[:, 27:]).max()) == 0.0

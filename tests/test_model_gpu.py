@@ -152,6 +152,8 @@ def test_data_parallel_two_ranks_equal_one_process():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    for dup in ("1", ""):      # duplicate shards: bit-identical step; real shards: the update agrees as a whole
+        env = dict(os.environ, VD_DP_DUP=dup) if dup else {k: v for k, v in os.environ.items() if k != "VD_DP_DUP"}
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (dup, r.stdout[-800:], r.stderr[-1500:])

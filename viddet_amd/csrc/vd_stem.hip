@@ -1,0 +1,224 @@
+// vd_stem.hip — the first convolution of Darknet-53 (3x3, 3 -> 32 channels, stride 1, pad 1) straight from the
+// NCHW frame batch, forward and weight gradient.
+//
+// Reference: darknet stem `_conv2d(32, 3, 1, 1)` models/definitions/three_darknet.py:163-164 on the batch the
+// transforms produce as (B,3,H,W) fp32 (models/definitions/yolo/transforms.py:239-245).
+//
+// Cin = 3 gives K = 27: as a tile of the generic implicit GEMM 90 % of the MFMA K lanes would be padding, and the
+// 32-wide im2col that feeds it costs a 1.4 GB round trip per pass at batch 64 / 416x416.  Both directions are
+// HBM-bound here (forward writes B*H*W*32 outputs, the weight gradient reads as many gradients), so:
+//   forward   : one lane = one pixel x 32 channels on the fp32 VALU (864 FMAs against wave-uniform weights that the
+//               compiler keeps in SGPRs), 27 coalesced input loads per lane, output transposed through LDS so a wave
+//               stores 1 KB contiguous; optional BN fold + LeakyReLU (inference), bf16 output (bf16 inference) or raw
+//               output + per-block BatchNorm partial sums (training).
+//   wgrad     : D[32 co][27 k] = sum_px dz[px][co] * x[px + tap(k)][c(k)] on v_mfma_f32_32x32x2_f32 with BOTH operands
+//               straight from global memory - lane (co, pixel parity) reads dz coalesced, lane (k, pixel parity)
+//               gathers its frame value - no LDS, no im2col; per-block partial tiles + a fixed-order reduction.
+#include "vd_common.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC = 32;          // output channels
+constexpr int SK = 27;          // 3 * 3 * 3 real taps x channels; packed weight rows are 32 wide (k >= 27 zero)
+constexpr int SPX = 256;        // pixels per workgroup (one per lane)
+
+// w: fwd-packed [32][32] with k = (ky*3 + kx)*3 + c  (vd_pack_weight_fwd of the OIHW stem weight; k >= 27 are zero)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  void* __restrict__ out, int ldo, int N, int H, int W,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  float slope, int flags, float* __restrict__ stats_part) {
+    __shared__ float tile[SPX][SC + 1];           // +1: the transposing reads walk a column
+    const int tid = threadIdx.x;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t P = (int64_t)N * HW;
+    const int64_t pix = (int64_t)blockIdx.x * SPX + tid;
+    float acc[SC];
+#pragma unroll
+    for (int c = 0; c < SC; ++c) acc[c] = 0.f;
+    if (pix < P) {
+        const int n = (int)(pix / HW);
+        const int r = (int)(pix - (int64_t)n * HW);
+        const int y = r / W, xx = r - y * W;
+        const float* xn = x + (int64_t)n * 3 * HW;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = xx + kx - 1;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = ok ? xn[(int64_t)c * HW + (int64_t)iy * W + ix] : 0.f;
+                    const int k = (ky * 3 + kx) * 3 + c;
+#pragma unroll
+                    for (int co = 0; co < SC; ++co) acc[co] = fmaf(v, w[co * 32 + k], acc[co]);   // w: wave-uniform
+                }
+            }
+    }
+    // fused BatchNorm statistics of the raw outputs (training): per-block column sums, one table row per block
+    if (stats_part) {
+        __shared__ float red[4][2 * SC];
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            float s1 = acc[c], s2 = acc[c] * acc[c];       // acc = 0 for lanes past the last pixel
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (lane == 0) {
+                red[wave][c] = s1;
+                red[wave][SC + c] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * SC)
+            stats_part[(int64_t)blockIdx.x * 2 * SC + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+#pragma unroll
+    for (int c = 0; c < SC; ++c) {
+        float v = acc[c];
+        if (flags & VD_EPI_AFFINE) v = v * scale[c] + shift[c];
+        if (flags & VD_EPI_LEAKY) v = v > 0.f ? v : v * slope;
+        tile[tid][c] = v;
+    }
+    __syncthreads();
+    // 256 pixels x 32 channels = 2048 float4: lane i writes float4 (pixel i/8 + 32*j, channels 4*(i%8)..)
+    const int64_t p0 = (int64_t)blockIdx.x * SPX;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int pl = (tid >> 3) + 32 * j, c4 = (tid & 7) * 4;
+        if (p0 + pl < P) {
+            const f32x4 v = {tile[pl][c4], tile[pl][c4 + 1], tile[pl][c4 + 2], tile[pl][c4 + 3]};
+            if (OUT_BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (p0 + pl) * ldo + c4) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (p0 + pl) * ldo + c4) = v;
+            }
+        }
+    }
+}
+
+// Weight gradient.  One wave owns a run of pixels; per MFMA (K = 2 pixels): A[co = lane&31][px = lane>>5] = dz, coalesced
+// 128-B rows; B[px][k = lane&31] = x[n][c(k)][y + dy(k)][x + dx(k)] (zero outside the frame and for k >= 27).
+// part: [gridDim.x * 4 waves][32 co][32 k] partial tiles, summed in wave order by k_stem_wgrad_reduce.
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dz, int ldd,
+                                                    float* __restrict__ part, int N, int H, int W, int64_t px_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t HW = (int64_t)H * W, P = (int64_t)N * HW;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p_begin = gw * px_per_wave;
+    int64_t p_end = p_begin + px_per_wave;
+    if (p_end > P) p_end = P;
+    const int k = lane & 31, par = lane >> 5;
+    const bool k_ok = k < SK;
+    const int c = k_ok ? k % 3 : 0, tap = k_ok ? k / 3 : 0;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // pixel cursor of this lane (p_begin + par), advanced by 2 per step
+    int64_t p = p_begin + par;
+    int n = 0, y = 0, xx = 0;
+    if (p < P) {
+        n = (int)(p / HW);
+        const int r = (int)(p - (int64_t)n * HW);
+        y = r / W;
+        xx = r - y * W;
+    }
+    for (; p - par < p_end; p += 2) {                 // wave-uniform trip count (p - par is the step's first pixel)
+        const bool in_run = p < p_end;
+        const float a = in_run ? dz[p * ldd + k] : 0.f;                      // k doubles as co for the A operand
+        const int iy = y + dy, ix = xx + dx;
+        const bool ok = in_run && k_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float b = ok ? x[((int64_t)n * 3 + c) * HW + (int64_t)iy * W + ix] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        xx += 2;
+        while (xx >= W) { xx -= W; ++y; }
+        if (y >= H) { y -= H; ++n; }
+    }
+    float* dst = part + gw * (SC * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[co * 32 + (lane & 31)] = acc[r];
+    }
+}
+
+__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dwp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // 32 x 32 outputs
+    if (i >= SC * 32) return;
+    float s = 0.f;
+    int q = 0;
+    for (; q + 8 <= nparts; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(q + u) * (SC * 32) + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; q < nparts; ++q) s += part[(int64_t)q * (SC * 32) + i];
+    dwp[i] = s;
+}
+
+constexpr int64_t STEM_WG_WAVES = 4096;      // partial tiles: 4096 x 4 KB = 16 MB of workspace at most
+
+}  // namespace
+
+extern "C" {
+
+int vd_stem_conv_blocks(int N, int H, int W) { return (int)vd_cdiv((int64_t)N * H * W, SPX); }
+
+int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N, int H, int W, const float* scale,
+                 const float* shift, float slope, int flags, int out_bf16, float* stats_part, void* stream) {
+    VD_REQUIRE(x_nchw && wp && out && N > 0 && H > 0 && W > 0 && ldo >= SC && ldo % 4 == 0, "vd_stem_conv: bad args");
+    VD_REQUIRE(!(flags & VD_EPI_AFFINE) || (scale && shift), "vd_stem_conv: affine epilogue needs scale and shift");
+    VD_REQUIRE(!stats_part || (flags == 0 && !out_bf16), "vd_stem_conv: fused statistics need the raw fp32 output");
+    VD_REQUIRE((int64_t)N * H * W < (1ll << 31), "vd_stem_conv: pixel count overflows int32");
+    const int nb = vd_stem_conv_blocks(N, H, W);
+    if (out_bf16)
+        hipLaunchKernelGGL(k_stem_fwd<true>, dim3(nb), dim3(SPX), 0, (hipStream_t)stream, x_nchw, wp, out, ldo, N, H, W,
+                           scale, shift, slope, flags, stats_part);
+    else
+        hipLaunchKernelGGL(k_stem_fwd<false>, dim3(nb), dim3(SPX), 0, (hipStream_t)stream, x_nchw, wp, out, ldo, N, H, W,
+                           scale, shift, slope, flags, stats_part);
+    VD_CHECK_LAUNCH("vd_stem_conv");
+    return VD_OK;
+}
+
+int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W) {
+    const int64_t P = (int64_t)N * H * W;
+    int64_t waves = vd_cdiv(P, 256);                 // >= 128 MFMA steps per wave
+    if (waves > STEM_WG_WAVES) waves = STEM_WG_WAVES;
+    waves = vd_cdiv(waves, 4) * 4;
+    return waves * SC * 32 * (int64_t)sizeof(float);
+}
+
+int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
+                  void* stream) {
+    VD_REQUIRE(x_nchw && dz && dwp && N > 0 && H > 0 && W > 0 && ldd >= SC, "vd_stem_wgrad: bad args");
+    const int64_t need = vd_stem_wgrad_ws_bytes(N, H, W);
+    if (!ws || ws_bytes < need) {
+        vd_set_error("vd_stem_wgrad: workspace %lld < %lld", (long long)ws_bytes, (long long)need);
+        return VD_EWORKSPACE;
+    }
+    const int64_t P = (int64_t)N * H * W;
+    const int64_t waves = need / (SC * 32 * (int64_t)sizeof(float));
+    int64_t ppw = vd_cdiv(P, waves);
+    ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels, runs start on the lane parity
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, dz, ldd, (float*)ws, N, H, W, ppw);
+    VD_CHECK_LAUNCH("vd_stem_wgrad");
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4), dim3(256), 0, s, (const float*)ws, (int)waves, dwp);
+    VD_CHECK_LAUNCH("vd_stem_wgrad/reduce");
+    return VD_OK;
+}
+
+}  // extern "C"

@@ -683,8 +683,6 @@ class YOLOV3(object):
         if self.noback:
             for nm, c_, d_ in ROUTE_TENSORS:                                   # NCHW staging of the three inputs
                 bufs['in:' + nm] = torch.empty(B, c_, H // d_, W // d_, device=dev)
-        else:
-            bufs['col'] = torch.empty(B * self._k, H, W, 32, device=dev)
         if train:
             for n in self.nodes:
                 if isinstance(n, PoolNode) and n.type == 0:
@@ -710,7 +708,7 @@ class YOLOV3(object):
     # ------------------------------------------------------------------ program builders
     def _conv_desc(self, n, bufs, B, H, W, out, *, scale=None, shift=None, residual=None, leaky=False):
         d = ConvDesc()
-        x = bufs['col'] if n.stem else bufs[n.src]
+        x = bufs[n.src]
         Hi, Wi = H // n.div_in, W // n.div_in
         Ho, Wo = H // n.div_out, W // n.div_out
         d.in_, d.wp, d.out = x.data_ptr(), n.wp.data_ptr(), out.data_ptr()
@@ -735,13 +733,18 @@ class YOLOV3(object):
         return d
 
     def _add_input_stage(self, prog, bufs, B, H, W):
-        """Layout change of the network inputs: the frame batch goes NCHW -> 32-wide im2col for the stem; the three
-        cached feature maps of the no-backbone variant go NCHW -> NHWC."""
+        """Layout change of the network inputs: none for the frame batch (the stem kernel reads NCHW directly); the
+        three cached feature maps of the no-backbone variant go NCHW -> NHWC."""
         if self.noback:
             for nm, c_, d_ in ROUTE_TENSORS:
                 prog.add('vd_nchw_to_nhwc', bufs['in:' + nm].data_ptr(), bufs[nm].data_ptr(), B, c_, H // d_, W // d_)
-        else:
-            prog.add('vd_stem_im2col', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B * self._k, H, W, 1)
+
+    def _add_stem(self, prog, n, bufs, B, H, W, out, *, scale=None, shift=None, leaky=False, bf16=False, stats=None):
+        """vd_stem_conv: the 3 -> 32 stem straight from the NCHW batch (vd_stem.hip)."""
+        flags = (EPI_AFFINE if scale is not None else 0) | (EPI_LEAKY if leaky else 0)
+        prog.add('vd_stem_conv', bufs['in'].data_ptr(), n.wp.data_ptr(), out.data_ptr(), out.shape[-1], B * self._k, H, W,
+                 scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None,
+                 LEAKY_SLOPE, flags, 1 if bf16 else 0, stats, meta=self._flops(n, B, H, W, 'fwd'))
 
     def _stage_inputs(self, bufs, x):
         if self.noback:
@@ -766,6 +769,9 @@ class YOLOV3(object):
                     prog.add('vd_temporal_cat', xs.data_ptr(), o.data_ptr(), B, n.K, xs.shape[1] * xs.shape[2], xs.shape[3], 0)
                 else:
                     prog.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
+                continue
+            if n.stem:
+                self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True)
                 continue
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
@@ -820,17 +826,16 @@ class YOLOV3(object):
         dev = self.device
         lib = L.load()
         cp = lambda c: round_up(c, 64)
-        bufs = {'in': torch.empty(B, 3, H, W, device=dev),
-                'col': torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=dev)}
+        bufs = {'in': torch.empty(B, 3, H, W, device=dev)}
         for name, (c, div, ld, fr) in self.tensors.items():
             if name == 'in':
                 continue
             if name in self.head_names:
                 bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
             else:
-                bufs[name] = torch.empty(B, H // div, W // div, cp(c), dtype=torch.bfloat16, device=dev)
+                # zeros: the stem kernel writes 32 of its 64 padded channels and never touches the rest
+                bufs[name] = torch.zeros(B, H // div, W // div, cp(c), dtype=torch.bfloat16, device=dev)
         prog = Program()
-        prog.add('vd_stem_im2col_bf16', bufs['in'].data_ptr(), bufs['col'].data_ptr(), B, H, W, 1)
         packs = []
         s = L.stream_ptr()
         for n in self.nodes:
@@ -840,12 +845,17 @@ class YOLOV3(object):
                 prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
                          o.shape[1], o.shape[2], cp(n.cu) // 2, cp(n.cr) // 2)
                 continue
-            ci_p = 64 if n.stem else cp(n.cin)
+            if n.stem:
+                # fp32 master weights and BN fold on the fp32 VALU, bf16 output (vd_stem.hip)
+                self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True,
+                               bf16=True)
+                continue
+            ci_p = cp(n.cin)
             co_p = n.co_pad if n.head else cp(n.cout)
             wb = torch.empty(co_p * n.T * ci_p, dtype=torch.bfloat16, device=dev)
             packs.append((n, wb, co_p, ci_p))
             d = ConvDesc()
-            x = bufs['col'] if n.stem else bufs[n.src]
+            x = bufs[n.src]
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
             d.in_, d.wp, d.out = x.data_ptr(), wb.data_ptr(), bufs[n.dst].data_ptr()
@@ -913,7 +923,7 @@ class YOLOV3(object):
             key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.flags, of32)
             if key not in _TUNE_CACHE:
                 best, best_t = 2, None
-                for c in (1, 2, 3, 4, 5):
+                for c in (1, 2, 3, 4, 5, 6, 7):
                     d.tile = c
                     L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -991,6 +1001,9 @@ class YOLOV3(object):
             self._add_input_stage(prog, bufs, B, H, W)
             last = max(i for i, n in enumerate(self.nodes) if isinstance(n, ConvNode) and n.dst == ROUTE_TENSORS[-1][0])
             for n in self.nodes[:last + 1]:
+                if n.stem:
+                    self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True)
+                    continue
                 res = bufs[n.residual] if n.residual else None
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
                                     leaky=True)
@@ -1023,7 +1036,7 @@ class YOLOV3(object):
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
             if n.stem:
-                ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B * n.fr, Hi, Wi, 32, Ho, Wo, n.co_pad, 1, 1, 0))
+                ws_bytes = max(ws_bytes, int(L.load().vd_stem_wgrad_ws_bytes(B * n.fr, Hi, Wi)))
             else:
                 ws_bytes = max(ws_bytes, ops.wgrad_ws_bytes(B * n.fr, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.k, n.stride,
                                                             n.pad, n.kd, n.pad_d))
@@ -1076,9 +1089,19 @@ class YOLOV3(object):
                 seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
                 continue
             z = bufs['z:' + n.dst]
-            d = self._conv_desc(n, bufs, B, H, W, z)
-            seg.hold(d)
-            if self.fuse_bn_stats:
+            if n.stem:
+                # raw conv output + one row of BatchNorm partial sums per 256-pixel block (vd_stem.hip)
+                nb = L.load().vd_stem_conv_blocks(B * n.fr, H, W)
+                assert nb * 2 * n.cout <= stats_ws.numel(), "stats workspace too small"
+                self._add_stem(seg, n, bufs, B, H, W, z, stats=stats_ws.data_ptr())
+                seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), nb, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                d = None
+            else:
+                d = self._conv_desc(n, bufs, B, H, W, z)
+                seg.hold(d)
+            if d is None:
+                pass
+            elif self.fuse_bn_stats:
                 # BN statistics ride in the conv epilogue: one row of partial sums per M tile, reduced in fp64
                 d.stats_part = stats_ws.data_ptr()
                 autotune_desc(d)                                   # fixes the tile, hence the number of M tiles
@@ -1242,8 +1265,27 @@ class YOLOV3(object):
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
                         dz.data_ptr())
             # weight gradient straight into the gradient arena (same fwd-packed layout as the weights)
+            if n.stem:
+                # both operands straight from global memory: the NCHW batch and dz (vd_stem.hip)
+                wargs = ('vd_stem_wgrad', bufs['in'].data_ptr(), dz.data_ptr(), n.co_pad, n.gwp.data_ptr(), B * n.fr, Hi, Wi)
+                if side is not None:
+                    e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
+                    seg.add_py(ev_record(e_ready, False))
+                    seg.add_py(ev_wait(e_ready, True))
+                    seg.add(*wargs, ws_w.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'), stream=side)
+                    seg.add_py(ev_record(e_done, True))
+                    seg.hold(e_ready, e_done)
+                    dz_free[slot] = e_done
+                    last_side[0] = e_done
+                else:
+                    seg.add(*wargs, ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
+                bucket_acc[0] += n.w_numel
+                if self.bucketed_allreduce:            # the stem is the first conv: its bucket closes the arena
+                    seg.add_py(self._bucket_launcher(n.w_off, bucket_hi[0], side))
+                    bucket_hi[0], bucket_acc[0] = n.w_off, 0
+                continue
             wd_ = WgradDesc()
-            xin = bufs['col'] if n.stem else bufs[n.src]
+            xin = bufs[n.src]
             wd_.in_, wd_.dout, wd_.dwp = xin.data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
             wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B * n.fr, Hi, Wi, n.ci_eff
             wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, n.co_pad

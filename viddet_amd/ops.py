@@ -182,6 +182,21 @@ def stem_im2col(x, col, nchw):
 # --------------------------------------------------------------------------------------------
 # batch norm
 # --------------------------------------------------------------------------------------------
+def stem_conv(x_nchw, wp, out, *, scale=None, shift=None, leaky=False, slope=0.1, stats_part=None):
+    """Direct stem conv (3x3, 3->32) from the NCHW fp32 batch; out NHWC fp32 or bf16 [N,H,W,32]."""
+    N, _, H, W = x_nchw.shape
+    flags = (EPI_AFFINE if scale is not None else 0) | (EPI_LEAKY if leaky else 0)
+    check(_lib().vd_stem_conv(ptr(x_nchw), ptr(wp), ptr(out), out.shape[-1], N, H, W, ptr(scale), ptr(shift), slope, flags,
+                              1 if out.dtype == torch.bfloat16 else 0, ptr(stats_part), _s()), "vd_stem_conv")
+
+
+def stem_wgrad(x_nchw, dz, dwp, ws):
+    """Weight gradient of the stem: dwp [32][32] fwd-packed from x (N,3,H,W) and dz [N,H,W,ldd]."""
+    N, _, H, W = x_nchw.shape
+    check(_lib().vd_stem_wgrad(ptr(x_nchw), ptr(dz), dz.shape[-1], ptr(dwp), N, H, W, ptr(ws),
+                               ws.numel() * ws.element_size(), _s()), "vd_stem_wgrad")
+
+
 def bn_stats(x2d_rows, C_, x, sums, ws):
     check(_lib().vd_bn_stats(ptr(x), x2d_rows, C_, ptr(sums), ptr(ws), ws.numel() * ws.element_size(), _s()),
           "vd_bn_stats")
