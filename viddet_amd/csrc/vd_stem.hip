@@ -7,8 +7,8 @@
 // Cin = 3 gives K = 27: as a tile of the generic implicit GEMM 90 % of the MFMA K lanes would be padding, and the
 // 32-wide im2col that feeds it costs a 1.4 GB round trip per pass at batch 64 / 416x416.  Both directions are
 // HBM-bound here (forward writes B*H*W*32 outputs, the weight gradient reads as many gradients), so:
-//   forward   : one lane = one pixel x 32 channels on the fp32 VALU (864 FMAs against wave-uniform weights that the
-//               compiler keeps in SGPRs), 27 coalesced input loads per lane, output transposed through LDS so a wave
+//   forward   : one lane = one pixel x 32 channels on the fp32 VALU (864 FMAs against weights broadcast from LDS),
+//               27 coalesced input loads per lane, output transposed through LDS so a wave
 //               stores 1 KB contiguous; optional BN fold + LeakyReLU (inference), bf16 output (bf16 inference) or raw
 //               output + per-block BatchNorm partial sums (training).
 //   wgrad     : D[32 co][27 k] = sum_px dz[px][co] * x[px + tap(k)][c(k)] on v_mfma_f32_32x32x2_f32 with BOTH operands
@@ -31,7 +31,12 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   float slope, int flags, float* __restrict__ stats_part) {
     __shared__ float tile[SPX][SC + 1];           // +1: the transposing reads walk a column
+    // weights transposed to [k][co] in LDS: for one k the 32 output-channel weights are 8 broadcast ds_read_b128
+    // (every lane the same address).  Kept in SGPRs they spilled: 864 values against 100 scalar registers.
+    __shared__ __attribute__((aligned(16))) float wT[SK][SC];
     const int tid = threadIdx.x;
+    for (int i = tid; i < SK * SC; i += SPX) wT[i / SC][i % SC] = w[(i % SC) * 32 + i / SC];
+    __syncthreads();
     const int64_t HW = (int64_t)H * W;
     const int64_t P = (int64_t)N * HW;
     const int64_t pix = (int64_t)blockIdx.x * SPX + tid;
@@ -43,20 +48,33 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
         const int r = (int)(pix - (int64_t)n * HW);
         const int y = r / W, xx = r - y * W;
         const float* xn = x + (int64_t)n * 3 * HW;
+        // the 27 frame values first (branch-free: out-of-frame taps read pixel 0 and are zeroed), then a pure
+        // LDS-read + FMA stream per k - with the loads inside that stream the compiler parked all 864 weights in
+        // registers and scratch while waiting for them
+        float xv[SK];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int iy = y + ky - 1, ix = xx + kx - 1;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int64_t o = ok ? (int64_t)iy * W + ix : 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float v = ok ? xn[(int64_t)c * HW + (int64_t)iy * W + ix] : 0.f;
-                    const int k = (ky * 3 + kx) * 3 + c;
-#pragma unroll
-                    for (int co = 0; co < SC; ++co) acc[co] = fmaf(v, w[co * 32 + k], acc[co]);   // w: wave-uniform
+                    const float t = xn[(int64_t)c * HW + o];
+                    xv[(ky * 3 + kx) * 3 + c] = ok ? t : 0.f;
                 }
             }
+#pragma unroll
+        for (int k = 0; k < SK; ++k) {
+#pragma unroll
+            for (int c4 = 0; c4 < SC; c4 += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wT[k][c4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c4 + e] = fmaf(xv[k], wv[e], acc[c4 + e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // keep each k's weight reads next to its FMAs
+        }
     }
     // fused BatchNorm statistics of the raw outputs (training): per-block column sums, one table row per block
     if (stats_part) {

@@ -44,17 +44,30 @@ __device__ __forceinline__ Box decode_box(const float* raw, int x, int y, float 
 // ------------------------------------------------------------------------------------------
 // inference: decode + valid_thresh filter
 // ------------------------------------------------------------------------------------------
+// Candidates are collected per workgroup in LDS and published with ONE global atomic per workgroup: a returning
+// atomic on the 32 per-image counters for every (cell, anchor, class chunk) that passes was a latency chain per wave
+// and ~7500 contended atomics per counter (1.1 ms at batch 32, 608x608 for 0.25 GB of input).
+constexpr int DF_LCAP = 2048;            // LDS candidate buffer per workgroup; beyond it, appends go straight to global
+
 __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, float thresh,
                                                        float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_row, int cap,
                                                        int32_t* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float lscore[DF_LCAP];
+    __shared__ int32_t lrow[DF_LCAP];
+    __shared__ int lcount, lfill, gbase;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int npred = 5 + h.C, A = 3 * npred;
     float* row = smem + wave * (A + 4);
     const int R0 = h.g[0] * h.g[0], R1 = h.g[1] * h.g[1], R2 = h.g[2] * h.g[2];
     const int R = R0 + R1 + R2;
+    if (threadIdx.x == 0) {
+        lcount = 0;
+        lfill = 1 << 30;                      // base of the first reservation that did not fit (none yet)
+    }
+    __syncthreads();
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         int s, pix, rowbase;
         if (r < R0) { s = 0; pix = r; rowbase = 0; }
@@ -82,14 +95,30 @@ __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, flo
                     }
                     const unsigned long long m = __ballot(pass);
                     if (m) {
+                        const int n = (int)__popcll(m);
                         int base = 0;
-                        if (lane == 0) base = atomicAdd(&counts[b], (int)__popcll(m));
+                        if (lane == 0) base = atomicAdd(&lcount, n);                  // LDS atomic
                         base = __shfl(base, 0);
-                        if (pass) {
-                            const int slot = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-                            if (slot < cap) {
-                                cand_score[(int64_t)b * cap + slot] = score;
-                                cand_row[(int64_t)b * cap + slot] = rowbase + c * gg3 + pix * 3 + a;
+                        const int rowid = rowbase + c * gg3 + pix * 3 + a;
+                        if (base + n <= DF_LCAP) {
+                            if (pass) {
+                                const int slot = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+                                lscore[slot] = score;
+                                lrow[slot] = rowid;
+                            }
+                        } else {                                                        // LDS buffer full: publish directly
+                            int gb = 0;
+                            if (lane == 0) {
+                                atomicMin(&lfill, base);
+                                gb = atomicAdd(&counts[b], n);
+                            }
+                            gb = __shfl(gb, 0);
+                            if (pass) {
+                                const int slot = gb + (int)__popcll(m & ((1ull << lane) - 1ull));
+                                if (slot < cap) {
+                                    cand_score[(int64_t)b * cap + slot] = score;
+                                    cand_row[(int64_t)b * cap + slot] = rowid;
+                                }
                             }
                         }
                     }
@@ -97,6 +126,19 @@ __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, flo
             }
         }
         WAVE_SYNC();
+    }
+    __syncthreads();
+    // Reservations are handed out in order from 0: every one before the first that did not fit filled its slots, and
+    // every one after it starts past DF_LCAP and went to global - the LDS part is exactly [0, min(lcount, lfill)).
+    const int nl = lcount < lfill ? lcount : lfill;
+    if (threadIdx.x == 0) gbase = atomicAdd(&counts[b], nl);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += 256) {
+        const int slot = gbase + i;
+        if (slot < cap) {
+            cand_score[(int64_t)b * cap + slot] = lscore[i];
+            cand_row[(int64_t)b * cap + slot] = lrow[i];
+        }
     }
 }
 
