@@ -76,27 +76,6 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
             __builtin_amdgcn_sched_barrier(0);        // keep each k's weight reads next to its FMAs
         }
     }
-    // fused BatchNorm statistics of the raw outputs (training): per-block column sums, one table row per block
-    if (stats_part) {
-        __shared__ float red[4][2 * SC];
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int c = 0; c < SC; ++c) {
-            float s1 = acc[c], s2 = acc[c] * acc[c];       // acc = 0 for lanes past the last pixel
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                s1 += __shfl_xor(s1, o);
-                s2 += __shfl_xor(s2, o);
-            }
-            if (lane == 0) {
-                red[wave][c] = s1;
-                red[wave][SC + c] = s2;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * SC)
-            stats_part[(int64_t)blockIdx.x * 2 * SC + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    }
 #pragma unroll
     for (int c = 0; c < SC; ++c) {
         float v = acc[c];
@@ -105,6 +84,29 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
         tile[tid][c] = v;
     }
     __syncthreads();
+    // fused BatchNorm statistics of the raw outputs (training; flags == 0, so the tile holds them): column sums out of
+    // the LDS tile - 8 row segments x 32 columns per pass, then 64 lanes fold the 8 partials (rows past the last pixel
+    // hold zeros).  One table row per workgroup.  (Per-column wave shuffles cost 384 cross-lane ops per wave.)
+    if (stats_part) {
+        __shared__ float red[8][2 * SC];
+        const int c = tid & 31, seg = tid >> 5;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int r = seg * 32; r < seg * 32 + 32; ++r) {
+            const float v = tile[r][c];
+            s1 += v;
+            s2 += v * v;
+        }
+        red[seg][c] = s1;
+        red[seg][SC + c] = s2;
+        __syncthreads();
+        if (tid < 2 * SC) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q][tid];
+            stats_part[(int64_t)blockIdx.x * 2 * SC + tid] = t;
+        }
+    }
     // 256 pixels x 32 channels = 2048 float4: lane i writes float4 (pixel i/8 + 32*j, channels 4*(i%8)..)
     const int64_t p0 = (int64_t)blockIdx.x * SPX;
 #pragma unroll
@@ -151,16 +153,25 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
         y = r / W;
         xx = r - y * W;
     }
-    for (; p - par < p_end; p += 2) {                 // wave-uniform trip count (p - par is the step's first pixel)
-        const bool in_run = p < p_end;
-        const float a = in_run ? dz[p * ldd + k] : 0.f;                      // k doubles as co for the A operand
-        const int iy = y + dy, ix = xx + dx;
-        const bool ok = in_run && k_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const float b = ok ? x[((int64_t)n * 3 + c) * HW + (int64_t)iy * W + ix] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        xx += 2;
-        while (xx >= W) { xx -= W; ++y; }
-        if (y >= H) { y -= H; ++n; }
+    // batches of UNR steps: all 2*UNR loads of a batch are issued before its MFMAs (one step at a time left a single
+    // pair of loads in flight per wave: latency bound at 1.4 TB/s)
+    constexpr int UNR = 8;
+    for (; p - par < p_end; p += 2 * UNR) {           // wave-uniform trip count (p - par is the batch's first pixel)
+        float a[UNR], b[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t pu = p + 2 * u;
+            const bool in_run = pu < p_end;
+            a[u] = in_run ? dz[pu * ldd + k] : 0.f;                          // k doubles as co for the A operand
+            const int iy = y + dy, ix = xx + dx;
+            const bool ok = in_run && k_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            b[u] = ok ? x[((int64_t)n * 3 + c) * HW + (int64_t)iy * W + ix] : 0.f;
+            xx += 2;
+            while (xx >= W) { xx -= W; ++y; }
+            if (y >= H) { y -= H; ++n; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     float* dst = part + gw * (SC * 32);
 #pragma unroll
@@ -170,23 +181,28 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
     }
 }
 
-__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dwp) {
+// dst[chunk][i] = sum of part[q][i] over the chunk's slabs, in slab order; gridDim.y chunks (one for the final pass)
+__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // 32 x 32 outputs
     if (i >= SC * 32) return;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y;
+    int q = blockIdx.y * per;
+    int q1 = q + per;
+    if (q1 > nparts) q1 = nparts;
     float s = 0.f;
-    int q = 0;
-    for (; q + 8 <= nparts; q += 8) {
+    for (; q + 8 <= q1; q += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(q + u) * (SC * 32) + i];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; q < nparts; ++q) s += part[(int64_t)q * (SC * 32) + i];
-    dwp[i] = s;
+    for (; q < q1; ++q) s += part[(int64_t)q * (SC * 32) + i];
+    dst[(int64_t)blockIdx.y * (SC * 32) + i] = s;
 }
 
-constexpr int64_t STEM_WG_WAVES = 4096;      // partial tiles: 4096 x 4 KB = 16 MB of workspace at most
+constexpr int STEM_RED_CHUNKS = 64;          // first reduction level: 64 chunks of slabs, then one pass over the 64 rows
+constexpr int64_t STEM_WG_WAVES = 8192;      // partial tiles: 8192 x 4 KB = 32 MB of workspace at most
 
 }  // namespace
 
@@ -216,7 +232,7 @@ int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W) {
     int64_t waves = vd_cdiv(P, 256);                 // >= 128 MFMA steps per wave
     if (waves > STEM_WG_WAVES) waves = STEM_WG_WAVES;
     waves = vd_cdiv(waves, 4) * 4;
-    return waves * SC * 32 * (int64_t)sizeof(float);
+    return (waves + STEM_RED_CHUNKS) * SC * 32 * (int64_t)sizeof(float);
 }
 
 int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
@@ -228,14 +244,17 @@ int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int
         return VD_EWORKSPACE;
     }
     const int64_t P = (int64_t)N * H * W;
-    const int64_t waves = need / (SC * 32 * (int64_t)sizeof(float));
+    const int64_t waves = need / (SC * 32 * (int64_t)sizeof(float)) - STEM_RED_CHUNKS;
     int64_t ppw = vd_cdiv(P, waves);
-    ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels, runs start on the lane parity
+    ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, dz, ldd, (float*)ws, N, H, W, ppw);
     VD_CHECK_LAUNCH("vd_stem_wgrad");
-    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4), dim3(256), 0, s, (const float*)ws, (int)waves, dwp);
-    VD_CHECK_LAUNCH("vd_stem_wgrad/reduce");
+    float* lvl1 = (float*)ws + waves * (SC * 32);
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, STEM_RED_CHUNKS), dim3(256), 0, s, (const float*)ws, (int)waves, lvl1);
+    VD_CHECK_LAUNCH("vd_stem_wgrad/reduce1");
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, 1), dim3(256), 0, s, (const float*)lvl1, STEM_RED_CHUNKS, dwp);
+    VD_CHECK_LAUNCH("vd_stem_wgrad/reduce2");
     return VD_OK;
 }
 
