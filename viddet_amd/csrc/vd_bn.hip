@@ -117,8 +117,15 @@ __global__ __launch_bounds__(1024) void k_bn_sum_partials_l1(const float* __rest
     int r1 = r0 + chunk;
     if (r1 > nblk) r1 = nblk;
     double s = 0.0;
-    if (i < C2)
-        for (int b = r0 + sl; b < r1; b += 16) s += (double)part[(int64_t)b * C2 + i];
+    if (i < C2) {
+        int b = r0 + sl;
+        for (; b + 48 < r1; b += 64) {            // four rows in flight, added in row order
+            const float p0 = part[(int64_t)b * C2 + i], p1 = part[(int64_t)(b + 16) * C2 + i];
+            const float p2 = part[(int64_t)(b + 32) * C2 + i], p3 = part[(int64_t)(b + 48) * C2 + i];
+            s += (double)p0; s += (double)p1; s += (double)p2; s += (double)p3;
+        }
+        for (; b < r1; b += 16) s += (double)part[(int64_t)b * C2 + i];
+    }
     sh[sl][cx] = s;
     __syncthreads();
     if (sl == 0 && i < C2) {
