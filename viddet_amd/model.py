@@ -282,7 +282,7 @@ class ConvNode:
         self.div_out = div_in * stride
         self.bn, self.residual, self.stem, self.head = bn, residual, stem, head
         self.co_pad = round_up(cout, 32) if head else cout
-        self.ci_eff = 32 if stem else cin           # stem runs as 1x1 over the 32-wide im2col
+        self.ci_eff = 32 if stem else cin           # stem weights are kept as [32][32]: 27 taps x channels padded to 32
         self.T = 1 if stem else kd * k * k
 
     def taps(self):
