@@ -246,7 +246,7 @@ def test_conv_fused_bn_statistics(tile):
 
 
 def test_bn_sum_partials_tall_table():
-    """Two-level path (more than 2048 partial rows) of the fused-statistics reduction."""
+    """Two-level path (more than 256 partial rows) of the fused-statistics reduction."""
     from viddet_amd import lib as L
     rng = np.random.default_rng(70)
     nblk, c = 5000, 48

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_bn_sum_partials(const float* __restric
     }
 }
 
-constexpr int SUMP_DIRECT = 2048, SUMP_CHUNKS = 64;
+constexpr int SUMP_DIRECT = 256, SUMP_CHUNKS = 64;    // taller tables: two levels (a 2-block direct pass over 2048 rows took 150 us)
 
 // level 1 of the tall-table reduction: block (cb, r) sums rows [r*chunk, (r+1)*chunk) of 64 columns
 __global__ __launch_bounds__(1024) void k_bn_sum_partials_l1(const float* __restrict__ part, int nblk, int C2,
@@ -175,15 +175,18 @@ __global__ void k_bn_fold_eval(const float* __restrict__ gamma, const float* __r
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
+// Streaming kernels below: the launch makes gridDim.x * 256 a multiple of cvec (fixed_col_blocks), so a thread's float4
+// column col = i % cvec never changes along its grid-stride loop - the per-channel constants are loaded (and the fp64
+// sums converted) once per thread instead of once per element, and the 64-bit modulo leaves the loop.
 __global__ void k_bn_apply_leaky(const float* __restrict__ x, const float* __restrict__ scale,
                                  const float* __restrict__ shift, const float* __restrict__ res,
                                  float* __restrict__ y, int64_t n4, int cvec, float slope) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % cvec);
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(i0 % cvec);
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
+    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
-        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -202,25 +205,28 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restr
                                float slope, float* __restrict__ dx) {
     const int cvec = C >> 2;
     const float inv_count = (float)(1.0 / count);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % cvec);
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(i0 % cvec);                      // fixed along the loop (see k_bn_apply_leaky)
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[col];
+    f32x4 mg, mgx;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        mg[e] = (float)sums2[col * 4 + e] * inv_count;
+        mgx[e] = (float)sums2[C + col * 4 + e] * inv_count;
+    }
+    for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
-        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
-        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col];
-        const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[col];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = col * 4 + e;
-            const float mg = (float)sums2[c] * inv_count;
-            const float mgx = (float)sums2[C + c] * inv_count;
             const float u = v[e] * sc[e] + sh[e];
             const float g = u > 0.f ? d[e] : d[e] * slope;
             const float xh = (v[e] - mu[e]) * is[e];
-            o[e] = sc[e] * (g - mg - xh * mgx);
+            o[e] = sc[e] * (g - mg[e] - xh * mgx[e]);
         }
         reinterpret_cast<f32x4*>(dx)[i] = o;
     }
@@ -245,6 +251,16 @@ int stream_blocks(int64_t n) {
     int64_t nb = vd_cdiv(n, 256);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// block count with (blocks * 256) % cvec == 0, so that every thread of a grid-stride loop keeps its channel column
+int fixed_col_blocks(int64_t n4, int cvec) {
+    int a = 256, b = cvec;
+    while (b) { const int t = a % b; a = b; b = t; }          // a = gcd(256, cvec)
+    const int64_t step = cvec / a;
+    int64_t nb = stream_blocks(n4);
+    nb = vd_cdiv(nb, step) * step;
     return (int)nb;
 }
 
@@ -320,7 +336,7 @@ int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, co
                       int64_t M, int C, float slope, void* stream) {
     VD_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && C % 4 == 0, "vd_bn_apply_leaky: bad args");
     const int64_t n4 = M * (C / 4);
-    hipLaunchKernelGGL(k_bn_apply_leaky, dim3(stream_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+    hipLaunchKernelGGL(k_bn_apply_leaky, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        residual, y, n4, C / 4, slope);
     VD_CHECK_LAUNCH("vd_bn_apply_leaky");
     return VD_OK;
@@ -360,7 +376,7 @@ int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const f
     VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && dx && count > 0 && C % 4 == 0,
                "vd_bn_bwd_apply: bad args");
     const int64_t n4 = M * (C / 4);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(stream_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
                        save_mean, save_invstd, sums2, count, n4, C, slope, dx);
     VD_CHECK_LAUNCH("vd_bn_bwd_apply");
     return VD_OK;
