@@ -109,8 +109,12 @@ def main():
     net.initialize(init="he", seed=233, obj_bias=-4.0)
     if a.dtype == "bf16":
         if train:
-            raise SystemExit("--dtype bf16 is an inference path (training is fp32 like the reference)")
-        net.set_precision("bf16")
+            # mixed-precision training arithmetic (BASELINE configs[4] family): fp32 tensors, accumulation and optimiser;
+            # convolution products on bf16-rounded operands (VD_MATH_BF16).  NOT the configs[2] headline, which is fp32.
+            from viddet_amd.model import set_conv_math
+            set_conv_math("bf16")
+        else:
+            net.set_precision("bf16")
     x_np, gt_np, ids_np = synthetic_batch(B * K, S, C, 233 + rank)
     if K > 1:                      # B windows of K frames; the labels are the centre frame's (one gt set per window)
         x_np = x_np.reshape(B, K, 3, S, S)
@@ -225,7 +229,8 @@ def main():
         ach = ig[0] / (ig[1] * 1e-3) / 1e12
         if a.dtype == "bf16":
             peak = PEAK_BF16_MFMA_TFLOPS
-            kname = "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)"
+            kname = ("k_conv_igemm (fp32 tensors, one bf16 MFMA term per product block)" if train else
+                     "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)")
             math = None
         else:
             # fp32 convolutions run in one of two product arithmetics, chosen per launch record by the plan-time
@@ -289,6 +294,9 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (("temporal-YOLO (k=%d frame windows) training, %d windows/GPU, %dx%d, fp32, fwd+bwd+"
                                      "SGD-momentum (BASELINE configs[3] family)" % (K, B, S, S)) if (train and K > 1) else
+                                    ("yolo3_darknet53_coco training, batch %d/GPU, %dx%d, bf16 conv products on fp32 tensors "
+                                     "(fp32 accumulate / BN / loss / SGD), fwd+bwd+SGD-momentum (BASELINE configs[4] "
+                                     "arithmetic on the configs[2] shape)" % (B, S, S)) if a.dtype == "bf16" else
                                     "yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
                                     "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),

@@ -41,6 +41,10 @@ extern "C" {
  * bits) and six of the nine partial products are accumulated in fp32 on the bf16 matrix pipe; the dropped terms are
  * below 2^-23 of the product (one fp32 rounding).  Storage, accumulation and the epilogue stay fp32. */
 #define VD_MATH_SPLIT    16
+/* VD_MATH_BF16: products on bf16-ROUNDED operands (only the leading piece of the split: one bf16 MFMA per product
+ * block), fp32 tensors / accumulation / epilogues unchanged - the mixed-precision training arithmetic of BASELINE
+ * configs[4]; results are bf16-accurate (2^-8 per operand), NOT fp32-accurate.  Same kernels and tiles as VD_MATH_SPLIT. */
+#define VD_MATH_BF16     32
 
 const char* vd_last_error(void);
 int vd_version(void);

@@ -157,3 +157,39 @@ def test_data_parallel_two_ranks_equal_one_process():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
                            text=True, timeout=600, env=env)
         assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (dup, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_training_step_in_bf16_products():
+    """set_conv_math('bf16'): convolution products on bf16-rounded operands, everything else fp32 (the mixed-precision
+    training arithmetic of BASELINE configs[4]).  Losses within 3 % of the fp64 oracle's, gradients correlated to it."""
+    from viddet_amd import model as M
+    M.set_conv_math("bf16")
+    try:
+        b, c, size, m = 2, 4, 64, 3
+        net, P = _mk_net(c, 6, obj_bias=-1.0)
+        rng = np.random.default_rng(6)
+        x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+        gt, tg = _targets(rng, b, c, size, m)
+        out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+        net.backward()
+        torch.cuda.synchronize()
+        used = [bool(a[0]._obj.flags & 32) for seg in net._last_train['fwd'] + net._last_train['bwd'] if hasattr(seg, 'recs')
+                for (fn_, _, a) in seg.recs if fn_ in ('vd_conv_igemm', 'vd_conv_wgrad')]
+        assert sum(used) > 100, "the bf16-product arithmetic was not selected"
+        onet = ON.Net(P, c)
+        losses_r, G, _ = onet.train_step(x.astype(np.float64), gt, *tg)
+        for i in range(4):
+            assert np.all(np.abs(out[i].cpu().numpy() - losses_r[i]) <= 3e-2 * np.maximum(1.0, np.abs(losses_r[i]))), i
+        # bf16 rounding of every operand, through 75 layers whose deepest BatchNorms see 8 samples on this fixture,
+        # leaves the gradient close in direction to the oracle's, not equal: whole-gradient cosine, and per tensor
+        cos, dot, ng, nr = [], 0.0, 0.0, 0.0
+        for k in G.keys():
+            g, r_ = net.collect_params()[k].grad().cpu().numpy().ravel().astype(np.float64), G[k].ravel()
+            cos.append(float(g @ r_ / (np.linalg.norm(g) * np.linalg.norm(r_) + 1e-30)))
+            dot, ng, nr = dot + float(g @ r_), ng + float(g @ g), nr + float(r_ @ r_)
+        whole = dot / np.sqrt(ng * nr)
+        print("bf16-product gradients: whole cosine %.4f, per-tensor mean %.3f min %.3f" % (whole, np.mean(cos), min(cos)))
+        assert whole > 0.9 and np.mean(cos) > 0.7 and min(cos) > 0.3, (whole, np.mean(cos), min(cos))
+    finally:
+        M.set_conv_math(None)
+        M._TUNE_CACHE.clear()

@@ -157,3 +157,40 @@ def test_split_fused_bn_statistics():
         s2 = part[:mt, co:].double().sum(0).cpu().numpy()
         assert np.abs(s1 - ref.sum((0, 2, 3))).max() < 2e-3
         assert np.abs(s2 - (ref ** 2).sum((0, 2, 3))).max() < 2e-3 * max(1.0, float((ref ** 2).sum((0, 2, 3)).max()) / 100)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_bf16_products_forward_and_gradients(tile):
+    """VD_MATH_BF16: the same kernels with only the leading bf16 piece of each operand (one MFMA term): results carry
+    the bf16 rounding of the operands (2^-8 each) and nothing worse - rms error within 1e-2 of the output rms and well
+    above the fp32 error (the mode really rounds)."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k = 3, 128, 13, 11, 160, 3
+    rng, x, wt = _mk(n, ci, h, w, co, k, 200 + tile)
+    xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+    ref = R.conv2d(x, wt, 1, 1)
+    out = torch.empty(n, h, w, co, device="cuda")
+    ops.conv_fwd(xd, wp, out, k=k, stride=1, pad=1, Co=co, tile=tile, split='bf16')
+    torch.cuda.synchronize()
+    e = dev_nhwc_to_nchw(out) - ref
+    rel = float(np.sqrt((e ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+    assert 5e-4 < rel < 1e-2, rel
+    if tile == 1:
+        dy = rng.standard_normal((n, co, h, w))
+        dx_ref, dw_ref = R.conv2d_backward(x, wt, dy, 1, 1)
+        dyd = nchw_to_dev_nhwc(dy)
+        dwp = torch.empty(co, k * k * ci, device="cuda")
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        ops.conv_wgrad(xd, dyd, dwp, ws, k=k, stride=1, pad=1, Co=co, split='bf16')
+        dw = torch.empty(co, ci, k, k, device="cuda")
+        ops.unpack_weight(dwp, dw)
+        plan = ops.dgrad_plans(k, 1, 1, h, w)[0]
+        wpk = torch.empty(ci, len(plan["taps"]) * co, device="cuda")
+        ops.pack_weight_dgrad(wp, wpk, Co=co, Co_pad=co, Ci=ci, kd=1, kh=k, kw=k, tap_ids=plan["tap_ids"], src_packed=True)
+        dx = torch.empty(n, h, w, ci, device="cuda")
+        ops.conv_igemm(dyd, wpk, dx, N=n, Hi=h, Wi=w, Ci=co, Hg=h, Wg=w, in_stride=1, taps=plan["taps"], Ho=h, Wo=w,
+                       Co=ci, ldo=ci, split='bf16')
+        torch.cuda.synchronize()
+        for got, r_ in ((dw.cpu().numpy(), dw_ref), (dev_nhwc_to_nchw(dx), dx_ref)):
+            rel = float(np.sqrt(((got - r_) ** 2).mean()) / np.sqrt((r_ ** 2).mean()))
+            assert 5e-4 < rel < 1e-2, rel

@@ -59,7 +59,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 16-B slots of a plane are XOR-swizzled with bits 2..3 of the row: the 16 rows of a ds_read_b128 lane group then
 // fall on 16 distinct slots of the 64 banks, and the two rows a ds_write_b64 lane group stores (8 lanes x 8 B each)
 // fall on the two halves of the 32 write banks (192 B = 16 dwords mod 32) - both conflict-free without padding.
-constexpr int SP_ROWB = 192;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -101,8 +100,13 @@ struct RowInfo {
 // BS: instantiation with the fused BatchNorm-backward reductions in the epilogue (their accumulators would cost the
 // other instantiations registers, and the 8-wave fp32-MFMA tiles sit at the 128-VGPR occupancy edge)
 // (second launch bound: the 8-wave fp32-MFMA tiles run two workgroups per CU = 4 waves per SIMD = 128 VGPRs)
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false>
+// NPL: bf16 planes per operand in the split arithmetic - 3 = exact split, 6 partial products (fp32-accurate);
+// 1 = only the leading piece, ONE bf16 MFMA per product block (VD_MATH_BF16: bf16-rounded operands, fp32 accumulate).
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3>
 __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
+    static_assert(NPL == 3 || (NPL == 1 && SP), "planes");
+    constexpr int SP_ROWB = NPL * 64;          // LDS row of the split arithmetic: NPL planes of 32 bf16
+    constexpr int NTERM = NPL == 3 ? 6 : 1;
     static_assert(!M16 || SP, "the 16x16x32 shape exists for the bf16 operands of the split arithmetic");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
@@ -227,20 +231,28 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
                 uint2 h, m, l;
-                split3(ra[i], h, m, l);
                 char* r = a3 + (lrow + RPP * i) * SP_ROWB;
+                if (NPL == 3) {
+                    split3(ra[i], h, m, l);
+                    *reinterpret_cast<uint2*>(r + 64) = m;
+                    *reinterpret_cast<uint2*>(r + 128) = l;
+                } else {
+                    h = make_uint2(pk_bf16(ra[i][0], ra[i][1]), pk_bf16(ra[i][2], ra[i][3]));
+                }
                 *reinterpret_cast<uint2*>(r) = h;
-                *reinterpret_cast<uint2*>(r + 64) = m;
-                *reinterpret_cast<uint2*>(r + 128) = l;
             }
 #pragma unroll
             for (int i = 0; i < BP; ++i) {
                 uint2 h, m, l;
-                split3(rb[i], h, m, l);
                 char* r = b3 + (lrow + RPP * i) * SP_ROWB;
+                if (NPL == 3) {
+                    split3(rb[i], h, m, l);
+                    *reinterpret_cast<uint2*>(r + 64) = m;
+                    *reinterpret_cast<uint2*>(r + 128) = l;
+                } else {
+                    h = make_uint2(pk_bf16(rb[i][0], rb[i][1]), pk_bf16(rb[i][2], rb[i][3]));
+                }
                 *reinterpret_cast<uint2*>(r) = h;
-                *reinterpret_cast<uint2*>(r + 64) = m;
-                *reinterpret_cast<uint2*>(r + 128) = l;
             }
             return;
         }
@@ -259,18 +271,18 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             const int rkey = 2 * ((r16 >> 3) & 1);
             const char* a3 = As3 + (buf * BM + wm * TM * 32 + r16) * SP_ROWB + ((ch ^ rkey) << 4);
             const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + r16) * SP_ROWB + ((ch ^ rkey) << 4);
-            bf16x8 fa[2 * TM][3];
+            bf16x8 fa[2 * TM][NPL];
 #pragma unroll
             for (int mb = 0; mb < 2 * TM; ++mb)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < NPL; ++q)
                     fa[mb][q] = *reinterpret_cast<const bf16x8*>(a3 + mb * 16 * SP_ROWB + q * 64);
             constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
             for (int nb = 0; nb < 2 * TN; ++nb) {
-                bf16x8 fb[3];
+                bf16x8 fb[NPL];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(b3 + nb * 16 * SP_ROWB + q * 64);
+                for (int q = 0; q < NPL; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(b3 + nb * 16 * SP_ROWB + q * 64);
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -280,8 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                     const int e0 = 4 * (2 * (mb & 1) + (nb & 1));
                     f32x4 c = {A_[e0], A_[e0 + 1], A_[e0 + 2], A_[e0 + 3]};
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb][QA[t]], fb[QB[t]], c, 0, 0, 0);
+                    for (int t = 0; t < NTERM; ++t)
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb][NPL == 3 ? QA[t] : 0], fb[NPL == 3 ? QB[t] : 0], c, 0, 0, 0);
                     A_[e0] = c[0]; A_[e0 + 1] = c[1]; A_[e0 + 2] = c[2]; A_[e0 + 3] = c[3];
                 }
 #if VD_SETPRIO
@@ -296,9 +308,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             const int swz = (lane >> 2) & 3, hh = lane >> 5;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                bf16x8 fa[TM][3], fb[TN][3];
+                bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
                         fa[mi][q] = *reinterpret_cast<const bf16x8*>(a3 + mi * 32 * SP_ROWB + q * 64 + (((kc * 2 + hh) ^ swz) << 4));
@@ -312,12 +324,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                 __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < NTERM; ++t)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][QA[t]], fb[ni][QB[t]],
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][NPL == 3 ? QA[t] : 0],
+                                                                                  fb[ni][NPL == 3 ? QB[t] : 0],
                                                                                   acc[mi][ni], 0, 0, 0);
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
@@ -625,23 +638,29 @@ const float* zero_page() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s);
 
 template <int WM, int WN, int TM, int TN, bool XF, bool SP = false, bool M16 = false>
 int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
     // the in-load transform (XF) and the backward reductions never meet: one is a forward feature, one a dgrad one
-    if (!XF && d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true>(d, s);
-    return launch_igemm_bs<WM, WN, TM, TN, XF, SP, M16, false>(d, s);
+    if (SP && (d.flags & VD_MATH_BF16)) {          // one-plane arithmetic (training in bf16 products); no XF variant
+        if (d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, SP ? 1 : 3>(d, s);
+        return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 1 : 3>(d, s);
+    }
+    if (!XF && d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, 3>(d, s);
+    return launch_igemm_bs<WM, WN, TM, TN, XF, SP, M16, false, 3>(d, s);
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int lds = SP ? 2 * (BM + BN) * SP_ROWB : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
-    static_assert(lds <= 160 * 1024 && lds >= WM * WN * 32 * LDS_LD * 4, "LDS budget (operand stages; epilogue patches)");
+    constexpr int lds0 = SP ? 2 * (BM + BN) * NPL * 64 : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
+    constexpr int lds_epi = WM * WN * 32 * LDS_LD * 4 > WM * BN * 2 * 4 ? WM * WN * 32 * LDS_LD * 4 : WM * BN * 2 * 4;
+    constexpr int lds = lds0 > lds_epi ? lds0 : lds_epi;       // operand stages, or the epilogue patches if larger
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS>;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS, NPL>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
@@ -695,7 +714,7 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
 
 template <bool XF>
 int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
-    if (d.flags & VD_MATH_SPLIT) return dispatch_igemm_split<XF>(d, s);
+    if (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16)) return dispatch_igemm_split<XF>(d, s);
     const int tile = igemm_resolve_tile(d);
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, XF>(d, s);   // 128 x 128, 4 waves of 64x64
@@ -747,7 +766,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c
 
 // second launch bound = waves per SIMD the kernel must fit: two workgroups per CU for the fp32-MFMA tiles (the
 // 8-wave ones must stay within 128 VGPRs), one 8-wave workgroup for the split-math tiles
-template <int WM, int WN, int TM, int TN, bool XF, bool SP>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, int NPL = 3>
 __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
@@ -765,7 +784,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     // SP: bf16 planes h/m/l, pixel-major, [2 stages][3][WG_BP][BM] then [2][3][WG_BP][WG_BN]
     constexpr int APL = WG_BP * BM * 2, BPL = WG_BP * WG_BN * 2;      // bytes of one plane
     char* As3 = reinterpret_cast<char*>(smem);
-    char* Bs3 = As3 + 2 * 3 * APL;
+    char* Bs3 = As3 + 2 * NPL * APL;
+    constexpr int NTERM = NPL == 3 ? 6 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int Ktot = p.T * p.Ci;
@@ -874,27 +894,35 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
         if (SP) {
-            char* a3 = As3 + buf * 3 * APL + (alc & 31) * 2;
-            char* b3 = Bs3 + buf * 3 * BPL + (blc & 31) * 2;
+            char* a3 = As3 + buf * NPL * APL + (alc & 31) * 2;
+            char* b3 = Bs3 + buf * NPL * BPL + (blc & 31) * 2;
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 uint2 h, m, l;
-                split3(ra[i], h, m, l);
                 const int px = alpix + AROWS * i;
                 char* r = a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6);
+                if (NPL == 3) {
+                    split3(ra[i], h, m, l);
+                    *reinterpret_cast<uint2*>(r + APL) = m;
+                    *reinterpret_cast<uint2*>(r + 2 * APL) = l;
+                } else {
+                    h = make_uint2(pk_bf16(ra[i][0], ra[i][1]), pk_bf16(ra[i][2], ra[i][3]));
+                }
                 *reinterpret_cast<uint2*>(r) = h;
-                *reinterpret_cast<uint2*>(r + APL) = m;
-                *reinterpret_cast<uint2*>(r + 2 * APL) = l;
             }
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 uint2 h, m, l;
-                split3(rb[i], h, m, l);
                 const int px = blpix + BROWS * i;
                 char* r = b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6);
+                if (NPL == 3) {
+                    split3(rb[i], h, m, l);
+                    *reinterpret_cast<uint2*>(r + BPL) = m;
+                    *reinterpret_cast<uint2*>(r + 2 * BPL) = l;
+                } else {
+                    h = make_uint2(pk_bf16(rb[i][0], rb[i][1]), pk_bf16(rb[i][2], rb[i][3]));
+                }
                 *reinterpret_cast<uint2*>(r) = h;
-                *reinterpret_cast<uint2*>(r + BPL) = m;
-                *reinterpret_cast<uint2*>(r + 2 * BPL) = l;
             }
             return;
         }
@@ -907,13 +935,13 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     };
     auto compute = [&](int buf) {
         if (SP) {
-            const char* a3 = As3 + buf * 3 * APL;
-            const char* b3 = Bs3 + buf * 3 * BPL;
+            const char* a3 = As3 + buf * NPL * APL;
+            const char* b3 = Bs3 + buf * NPL * BPL;
 #pragma unroll
             for (int kc = 0; kc < WG_BP / 16; ++kc) {
-                bf16x8 fa[TM][3], fb[TN][3];
+                bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
                         fa[mi][q] = tr_operand(a3 + q * APL, BM * 2, wm * TM * 32 + mi * 32, kc, lane);
@@ -923,12 +951,13 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                 }
                 constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < NTERM; ++t)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][QA[t]], fb[ni][QB[t]],
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][NPL == 3 ? QA[t] : 0],
+                                                                                  fb[ni][NPL == 3 ? QB[t] : 0],
                                                                                   acc[mi][ni], 0, 0, 0);
             }
             return;
@@ -1021,7 +1050,7 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
-bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & VD_MATH_SPLIT) && d.Co >= 64; }
+bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16)) && d.Co >= 64; }
 int wgrad_bm(const vd_wgrad_desc& d) {
     if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : (d.Co >= 128 ? 128 : 64);
     return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
@@ -1052,17 +1081,17 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
     return (int)s;
 }
 
-template <int WM, int WN, int TM, int TN, bool SP = false>
-void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool SP, int NPL>
+void launch_wgrad_n(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
     constexpr int BM = WM * TM * 32;
-    constexpr int lds = SP ? 2 * 3 * WG_BP * (BM + WG_BN) * 2 : 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
+    constexpr int lds = SP ? 2 * NPL * WG_BP * (BM + WG_BN) * 2 : 2 * WG_BP * (BM + WG_BN) * (int)sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!SP || BM >= 64, "the 64-B chunk swizzle of the split planes needs rows of >= 128 B");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false, SP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false, SP, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true, SP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true, SP, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
@@ -1070,11 +1099,17 @@ void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, h
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_do = zp - d.dout;
     if (d.in_scale)
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true, SP>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
-                           d, dst, splits, pps, zd_in, zd_do);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true, SP, NPL>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds,
+                           s, d, dst, splits, pps, zd_in, zd_do);
     else
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false, SP>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s,
-                           d, dst, splits, pps, zd_in, zd_do);
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false, SP, NPL>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds,
+                           s, d, dst, splits, pps, zd_in, zd_do);
+}
+
+template <int WM, int WN, int TM, int TN, bool SP = false>
+void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
+    if (SP && (d.flags & VD_MATH_BF16)) launch_wgrad_n<WM, WN, TM, TN, SP, SP ? 1 : 3>(d, dst, splits, pps, s);
+    else launch_wgrad_n<WM, WN, TM, TN, SP, 3>(d, dst, splits, pps, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1195,7 +1230,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
 int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
     if (!d) return 0;
     const int64_t M = (int64_t)d->N * d->Hg * d->Wg;
-    if (d->flags & VD_MATH_SPLIT) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
+    if (d->flags & (VD_MATH_SPLIT | VD_MATH_BF16)) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
     return (int)vd_cdiv(M, igemm_tile_bm(igemm_resolve_tile(*d)));
 }
 

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hi
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
+MATH_BF16 = 32         # products on bf16-rounded operands (one MFMA term), fp32 tensors and accumulation
 
 _fp = C.c_void_p
 

@@ -93,7 +93,8 @@ class Program:
                 rc = fn(*a, s)
                 e1.record()
                 if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
-                    meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT))
+                    meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT),
+                                bf16=bool(args[0]._obj.flags & L.MATH_BF16))
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
@@ -110,10 +111,21 @@ def fp32_math():
     'split' = three-way bf16 operand split on the bf16 matrix pipe (fp32-accurate), 'auto' = the
     plan-time autotuner times both per launch record and keeps the faster."""
     import os
-    m = os.environ.get("VD_FP32_MATH", "auto")
-    if m not in ("native", "split", "auto"):
-        raise ValueError("VD_FP32_MATH must be native|split|auto, got %r" % m)
+    m = _MATH_OVERRIDE[0] or os.environ.get("VD_FP32_MATH", "auto")
+    if m not in ("native", "split", "auto", "bf16"):
+        raise ValueError("VD_FP32_MATH must be native|split|auto|bf16, got %r" % m)
     return m
+
+
+_MATH_OVERRIDE = [None]
+
+
+def set_conv_math(mode):
+    """Process-wide product arithmetic of the fp32-tensor convolutions for programs built from now on: None (the
+    VD_FP32_MATH environment, default 'auto'), 'native', 'split', 'auto', or 'bf16' = products on bf16-rounded
+    operands with fp32 accumulation (VD_MATH_BF16; the mixed-precision training arithmetic, bf16-accurate)."""
+    assert mode in (None, "native", "split", "auto", "bf16")
+    _MATH_OVERRIDE[0] = mode
 
 
 def _tile_candidates(d, math):
@@ -126,11 +138,14 @@ def _tile_candidates(d, math):
             cands += [(0, 6), (0, 8)]
         else:
             cands += [(0, t) for t in (1, 2, 3, 4, 5)]
-    if math in ("split", "auto"):
+    if math in ("split", "auto", "bf16"):
+        fl = L.MATH_BF16 if math == "bf16" else L.MATH_SPLIT
         if d.Co <= 64:           # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
-            cands += [(L.MATH_SPLIT, t) for t in (3, 4, 7, 8)]
+            cands += [(fl, t) for t in (3, 4, 7, 8)]
         else:
-            cands += [(L.MATH_SPLIT, t) for t in (1, 2, 3, 4, 5, 6, 7, 8)]
+            cands += [(fl, t) for t in (1, 2, 3, 4, 5, 6, 7, 8)]
+        if math == "bf16" and d.Co <= 32:          # nothing narrower than 64 columns in the split tiles
+            cands = [(0, 7)]
     return cands
 
 
@@ -140,9 +155,9 @@ def autotune_desc(d, reps=3):
     the kernel's heuristic tile.  Tuning launches only rewrite buffers every real run rewrites first."""
     import os
     math = fp32_math()
-    base = d.flags & ~L.MATH_SPLIT
+    base = d.flags & ~(L.MATH_SPLIT | L.MATH_BF16)
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
-        d.flags = base | (L.MATH_SPLIT if math == "split" else 0)
+        d.flags = base | (L.MATH_SPLIT if math == "split" else (L.MATH_BF16 if math == "bf16" and d.Co > 32 else 0))
         return
     lib = L.load()
     s = L.stream_ptr()
@@ -177,6 +192,9 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     math = fp32_math()
     d.flags = 0
     if d.Co < 64 or math == "native":
+        return
+    if math == "bf16":
+        d.flags = L.MATH_BF16
         return
     if math == "split" or os.environ.get("VD_AUTOTUNE", "1") == "0":
         d.flags = L.MATH_SPLIT

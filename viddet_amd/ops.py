@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, check, ptr
+from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, MATH_BF16, check, ptr
 
 
 def round_up(v, m):
@@ -94,8 +94,8 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
         flags |= EPI_LEAKY
     if residual is not None:
         flags |= EPI_RESIDUAL
-    if split:
-        flags |= MATH_SPLIT
+    if split:                       # True / 'split': exact 3-plane split; 'bf16': one plane (bf16-rounded operands)
+        flags |= MATH_BF16 if split == 'bf16' else MATH_SPLIT
     d.flags, d.slope = flags, slope
     d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
     check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm")
@@ -125,7 +125,7 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
-    d.flags = MATH_SPLIT if split else 0
+    d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
     if need > ws.numel() * ws.element_size():
