@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef VD_KORDER
+#define VD_KORDER 1
+#endif
 #ifndef VD_SETPRIO
 #define VD_SETPRIO 1
 #endif
@@ -213,12 +216,22 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             const int64_t sel = boff[i] >= 0 ? o : zd_w;
             rb[i] = *reinterpret_cast<const f32x4*>(p.wp + sel);
         }
+#if VD_KORDER
+        // taps innermost: the T taps of one 32-channel chunk touch (almost) the same pixels, shifted
+        ++t_tap;
+        if (t_tap >= p.T) {
+            t_tap = 0;
+            c0 += BK;
+        }
+        tap_soff = tap_off(t_tap);
+#else
         c0 += BK;
         if (c0 >= p.Ci) {
             c0 = 0;
             ++t_tap;
             if (t_tap < p.T) tap_soff = tap_off(t_tap);
         }
+#endif
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
         if (SP) {
