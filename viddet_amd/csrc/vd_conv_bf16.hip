@@ -115,12 +115,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
             rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
         }
-        c0 += KCH;
-        if (c0 >= p.Ci) {
-            c0 = 0;
-            ++t_tap;
-            if (t_tap < p.T) tap_soff = tap_off(t_tap);
+        // taps innermost: the T taps of one channel chunk touch (almost) the same pixels, shifted (see vd_conv.hip)
+        ++t_tap;
+        if (t_tap >= p.T) {
+            t_tap = 0;
+            c0 += KCH;
         }
+        tap_soff = tap_off(t_tap);
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
         unsigned char* a = As + buf * BM * ROW_B;
