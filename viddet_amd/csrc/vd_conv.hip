@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef VD_WG_REMAP
+#define VD_WG_REMAP 1
+#endif
 #ifndef VD_KORDER
 #define VD_KORDER 1
 #endif
@@ -804,8 +807,13 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     const int Ktot = p.T * p.Ci;
     const int jtiles = (Ktot + WG_BN - 1) / WG_BN;
     const int mtiles = (p.Co + BM - 1) / BM;
-    // block -> (split, jtile, mtile)
+    // block -> (split, jtile, mtile); XCD-aware: a contiguous run of logical ids per XCD, i.e. whole pixel ranges
+    // (splits), so the dout / in panels of a split are fetched into ONE L2 and shared by its mtiles*jtiles blocks
+#if VD_WG_REMAP
+    int b = vd_xcd_remap(blockIdx.x, gridDim.x);
+#else
     int b = blockIdx.x;
+#endif
     const int tile_m = b % mtiles; b /= mtiles;
     const int tile_j = b % jtiles;
     const int split = b / jtiles;
