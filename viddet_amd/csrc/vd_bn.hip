@@ -104,7 +104,14 @@ __global__ __launch_bounds__(1024) void k_bn_sum_partials(const float* __restric
     }
 }
 
-constexpr int SUMP_DIRECT = 256, SUMP_CHUNKS = 64;    // taller tables: two levels (a 2-block direct pass over 2048 rows took 150 us)
+// tables taller than SUMP_DIRECT rows go through two levels with one chunk per ~SUMP_DIRECT rows (at most SUMP_CHUNKS):
+// a direct pass over 2048 rows of a 64-column table is 2 workgroups and 150 us; 64 chunks for a 300-row table is 26 us
+// of mostly idle launches
+constexpr int SUMP_DIRECT = 256, SUMP_CHUNKS = 64;
+inline int sump_chunks(int nblk) {
+    int c = (nblk + SUMP_DIRECT - 1) / SUMP_DIRECT;
+    return c > SUMP_CHUNKS ? SUMP_CHUNKS : c;
+}
 
 // level 1 of the tall-table reduction: block (cb, r) sums rows [r*chunk, (r+1)*chunk) of 64 columns
 __global__ __launch_bounds__(1024) void k_bn_sum_partials_l1(const float* __restrict__ part, int nblk, int C2,
@@ -140,7 +147,15 @@ __global__ void k_bn_sum_partials_l2(const double* __restrict__ in, int rows, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C2) return;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += in[(int64_t)r * C2 + i];
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {            // eight rows in flight, added in row order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = in[(int64_t)(r + u) * C2 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < rows; ++r) s += in[(int64_t)r * C2 + i];
     sums[i] = s;
 }
 
@@ -304,10 +319,11 @@ int vd_bn_sum_partials(const float* part, int nblk, int C, double* sums, void* w
         vd_set_error("vd_bn_sum_partials: workspace too small");
         return VD_EWORKSPACE;
     }
-    hipLaunchKernelGGL(k_bn_sum_partials_l1, dim3((unsigned)vd_cdiv(2 * C, 64), SUMP_CHUNKS), dim3(1024), 0, s, part, nblk, 2 * C,
+    const int chunks = sump_chunks(nblk);
+    hipLaunchKernelGGL(k_bn_sum_partials_l1, dim3((unsigned)vd_cdiv(2 * C, 64), chunks), dim3(1024), 0, s, part, nblk, 2 * C,
                        (double*)ws);
     VD_CHECK_LAUNCH("vd_bn_sum_partials/l1");
-    hipLaunchKernelGGL(k_bn_sum_partials_l2, dim3((unsigned)vd_cdiv(2 * C, 256)), dim3(256), 0, s, (const double*)ws, SUMP_CHUNKS,
+    hipLaunchKernelGGL(k_bn_sum_partials_l2, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(64), 0, s, (const double*)ws, chunks,
                        2 * C, sums);
     VD_CHECK_LAUNCH("vd_bn_sum_partials/l2");
     return VD_OK;
