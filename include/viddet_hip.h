@@ -189,6 +189,15 @@ int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_
 /* fp64 reduction of a partial table part[nblk][2C] (vd_conv_igemm stats_part) into sums[2C] */
 int64_t vd_bn_sum_partials_ws_bytes(int nblk, int C);
 int vd_bn_sum_partials(const float* part, int nblk, int C, double* sums, void* ws, int64_t ws_bytes, void* stream);
+/* The same reduction fused with what follows it (one launch for tables of up to 1024 rows, else the calls above):
+ * forward  = vd_bn_sum_partials + vd_bn_finalize;  backward = vd_bn_sum_partials + vd_bn_param_grads.  The fp64 sums
+ * are written as well.  (With SyncBN the unfused calls are used: the all-reduce sits between the two halves.) */
+int vd_bn_sum_finalize(const float* part, int nblk, int C, double* sums, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* scale, float* shift, float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
+                       void* stream);
+int vd_bn_sum_param_grads(const float* part, int nblk, int C, double* sums2, float* dgamma, float* dbeta, void* ws,
+                          int64_t ws_bytes, void* stream);
 /* from (possibly all-reduced) sums and total count: mean, biased var -> scale/shift for the
  * apply, saved mean/invstd for backward, running-stat update run = mom*run + (1-mom)*batch */
 int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,

@@ -180,6 +180,67 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count, int
     if (rvar) rvar[c] = rvar[c] * momentum + (float)var * (1.f - momentum);
 }
 
+// Fused tail of the BatchNorm statistics for tables of up to SUMP_FUSED rows: a workgroup owns 32 channels, sums BOTH of
+// their columns (c and C + c) of the partial table in fp64 - 16 row slices, fixed order, as k_bn_sum_partials - and
+// finishes in place.  MODE 0 (forward): sums -> scale/shift/mean/invstd + running statistics (k_bn_finalize).
+// MODE 1 (backward): sums2 -> dgamma/dbeta (k_bn_param_grads).  The fp64 sums are written too (SyncBN-free path only,
+// but bn_bwd_apply and tests read them).  Replaces 2-4 tiny launches on the critical path of every conv by one.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_bn_sum_fused(const float* __restrict__ part, int nblk, int C, double* __restrict__ sums,
+                                                       double count, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float momentum,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       float* __restrict__ scale, float* __restrict__ shift,
+                                                       float* __restrict__ smean, float* __restrict__ sinv,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh[16][64];
+    const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 32 + (cx & 31);               // channel; cx >> 5 selects the sum / sum-of-squares column
+    const int col = (cx >> 5) * C + ch;
+    double s = 0.0;
+    if (ch < C) {
+        const int C2 = 2 * C;
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {
+            const float p0 = part[(int64_t)b * C2 + col], p1 = part[(int64_t)(b + 16) * C2 + col];
+            const float p2 = part[(int64_t)(b + 32) * C2 + col], p3 = part[(int64_t)(b + 48) * C2 + col];
+            s += (double)p0; s += (double)p1; s += (double)p2; s += (double)p3;
+        }
+        for (; b < nblk; b += 16) s += (double)part[(int64_t)b * C2 + col];
+    }
+    sh[sl][cx] = s;
+    __syncthreads();
+    if (sl == 0 && ch < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sh[j][cx];
+        sums[col] = t;
+        sh[0][cx] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && ch < C) {
+        const double a = sh[0][threadIdx.x], bq = sh[0][32 + threadIdx.x];     // column c, column C + c
+        if (MODE == 0) {
+            const double mean = a / count;
+            double var = bq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[ch] * invstd;
+            scale[ch] = sc;
+            shift[ch] = beta[ch] - (float)mean * sc;
+            if (smean) smean[ch] = (float)mean;
+            if (sinv) sinv[ch] = invstd;
+            if (rmean) rmean[ch] = rmean[ch] * momentum + (float)mean * (1.f - momentum);
+            if (rvar) rvar[ch] = rvar[ch] * momentum + (float)var * (1.f - momentum);
+        } else {
+            dbeta[ch] = (float)a;
+            dgamma[ch] = (float)bq;
+        }
+    }
+}
+
+constexpr int SUMP_FUSED = 1024;          // rows up to which the fused single-launch tail is used
+
 __global__ void k_bn_fold_eval(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                int C, float* __restrict__ scale, float* __restrict__ shift) {
@@ -337,6 +398,39 @@ int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, 
                        C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
     VD_CHECK_LAUNCH("vd_bn_finalize");
     return VD_OK;
+}
+
+int vd_bn_sum_finalize(const float* part, int nblk, int C, double* sums, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* scale, float* shift, float* save_mean, float* save_invstd, void* ws, int64_t ws_bytes,
+                       void* stream) {
+    VD_REQUIRE(part && sums && gamma && beta && scale && shift && nblk > 0 && C > 0 && count > 0, "vd_bn_sum_finalize: bad args");
+    if (nblk <= SUMP_FUSED) {
+        hipLaunchKernelGGL(k_bn_sum_fused<0>, dim3((unsigned)vd_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, sums,
+                           count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd,
+                           (float*)nullptr, (float*)nullptr);
+        VD_CHECK_LAUNCH("vd_bn_sum_finalize");
+        return VD_OK;
+    }
+    const int rc = vd_bn_sum_partials(part, nblk, C, sums, ws, ws_bytes, stream);
+    if (rc != VD_OK) return rc;
+    return vd_bn_finalize(sums, count, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
+                          save_invstd, stream);
+}
+
+int vd_bn_sum_param_grads(const float* part, int nblk, int C, double* sums2, float* dgamma, float* dbeta, void* ws,
+                          int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(part && sums2 && dgamma && dbeta && nblk > 0 && C > 0, "vd_bn_sum_param_grads: bad args");
+    if (nblk <= SUMP_FUSED) {
+        hipLaunchKernelGGL(k_bn_sum_fused<1>, dim3((unsigned)vd_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, sums2,
+                           1.0, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, dgamma, dbeta);
+        VD_CHECK_LAUNCH("vd_bn_sum_param_grads");
+        return VD_OK;
+    }
+    const int rc = vd_bn_sum_partials(part, nblk, C, sums2, ws, ws_bytes, stream);
+    if (rc != VD_OK) return rc;
+    return vd_bn_param_grads(sums2, C, dgamma, dbeta, stream);
 }
 
 int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -76,6 +76,8 @@ SIGNATURES = {
     "vd_bn_sum_partials_ws_bytes": (_i64, [_i, _i]),
     "vd_bn_sum_partials": (_i, [_p, _i, _i, _p, _p, _i64, _p]),
     "vd_bn_finalize": (_i, [_p, _d, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "vd_bn_sum_finalize": (_i, [_p, _i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "vd_bn_sum_param_grads": (_i, [_p, _i, _i, _p, _p, _p, _p, _i64, _p]),
     "vd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "vd_bn_apply_leaky": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
     "vd_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),

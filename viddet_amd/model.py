@@ -1112,7 +1112,7 @@ class YOLOV3(object):
                 nb = L.load().vd_stem_conv_blocks(B * n.fr, H, W)
                 assert nb * 2 * n.cout <= stats_ws.numel(), "stats workspace too small"
                 self._add_stem(seg, n, bufs, B, H, W, z, stats=stats_ws.data_ptr())
-                seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), nb, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                table_rows = nb
                 d = None
             else:
                 d = self._conv_desc(n, bufs, B, H, W, z)
@@ -1120,24 +1120,34 @@ class YOLOV3(object):
             if d is None:
                 pass
             elif self.fuse_bn_stats:
+                table_rows = None
                 # BN statistics ride in the conv epilogue: one row of partial sums per M tile, reduced in fp64
                 d.stats_part = stats_ws.data_ptr()
                 autotune_desc(d)                                   # fixes the tile, hence the number of M tiles
                 mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
                 assert mt * 2 * n.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
                 seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
-                seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), mt, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                table_rows = mt
             else:
                 seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
                 seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                table_rows = None
             count = float(M)
-            if self._syncbn(n):
-                sums = n.sums
-                seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
-                count = float(M * world)
-            seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, n.gamma.data_ptr(), n.beta.data_ptr(), BN_EPS,
-                    BN_MOMENTUM, n.rmean.data_ptr(), n.rvar.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
-                    n.b_mean.data_ptr(), n.b_invstd.data_ptr())
+            fin = (n.gamma.data_ptr(), n.beta.data_ptr(), BN_EPS, BN_MOMENTUM, n.rmean.data_ptr(), n.rvar.data_ptr(),
+                   n.b_scale.data_ptr(), n.b_shift.data_ptr(), n.b_mean.data_ptr(), n.b_invstd.data_ptr())
+            if table_rows is not None and not self._syncbn(n):
+                # partial table -> fp64 sums -> scale / shift / running statistics in ONE launch (short tables)
+                seg.add('vd_bn_sum_finalize', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), count, *fin,
+                        ws.data_ptr(), ws_bytes)
+            else:
+                if table_rows is not None:
+                    seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), ws.data_ptr(),
+                            ws_bytes)
+                if self._syncbn(n):
+                    sums = n.sums
+                    seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
+                    count = float(M * world)
+                seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, *fin)
             res = bufs[n.residual].data_ptr() if n.residual else None
             seg.add('vd_bn_apply_leaky', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
                     bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE)
@@ -1271,7 +1281,8 @@ class YOLOV3(object):
                     seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                             n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
                             ws.data_ptr(), ws_bytes)
-                seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
+                if n.name not in fused_bwd:      # (fused: the gamma/beta gradients came with the table reduction)
+                    seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
                 count = float(M)
                 if self._syncbn(n):
                     s2 = n.sums2
@@ -1374,8 +1385,8 @@ class YOLOV3(object):
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
                     bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans))
                 if fuse_m is not None:
-                    seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
-                            ws.data_ptr(), ws_bytes)
+                    seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
+                            fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
                     fused_bwd.add(fuse_m.name)
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))          # join: the optimiser / all-reduce see every gradient
