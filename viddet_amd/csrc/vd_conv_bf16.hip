@@ -23,12 +23,38 @@ constexpr int KCH = 64;                 // bf16 channels per K-step
 
 __device__ __attribute__((aligned(64))) float g_zero_page_b[64];
 
+// developer build (-DVD_STAMP=1, tools/stamp_bf16.py): wave 0 of one mid-grid workgroup records s_memtime at the
+// phase boundaries of the kernel
+#ifndef VD_STAMP
+#define VD_STAMP 0
+#endif
+#if VD_STAMP
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+// n / d for d >= 1 with rcp = 0xFFFFFFFF / d + 1: the multiply-high overshoots the quotient by at most one
+__device__ __forceinline__ unsigned udiv_rcp(unsigned n, unsigned d, unsigned rcp) {
+    unsigned q = d == 1u ? n : __umulhi(n, rcp);
+    q -= (q * d > n) ? 1u : 0u;
+    return q;
+}
+
 struct RowInfoB {
     int64_t off;     // element offset (bf16) of (pixel of tap (0,0,0), channel 8*(tid&7))
     unsigned mask;
 };
 
-template <int WM, int WN, int TM, int TN, bool OUT_F32>
+// PAIR (Ci == 32, the two first-stage 3x3 convs): a K-step is still one 128-byte LDS row, made of TWO taps x 32
+// channels - the packed weight row [T][32] is already contiguous that way, and each lane's 16-byte chunk picks its
+// tap (chunk >> 2) - so 32-channel activations are stored unpadded and a 9-tap conv takes 5 K-steps instead of 9
+// half-empty ones.
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
                                                                   const int64_t zd_w) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -50,33 +76,47 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     const int tile_n = lid % ntile, tile_m = lid / ntile;
     const int Ktot = p.T * p.Ci;
     const int lrow = tid >> 3;
-    const int lc8 = (tid & 7) * 8;            // bf16 element offset of this lane's 16-byte chunk
+    const int lc8 = (tid & 7) * 8;            // bf16 element offset of this lane's 16-byte chunk (within the K-step)
+    const int lca = PAIR ? (tid & 3) * 8 : lc8;   // ... within its pixel's channel run
+    const int ptap = PAIR ? ((tid >> 2) & 1) : 0; // PAIR: which tap of the K-step's pair this lane gathers
 
+    STAMP(0);
+    // Row geometry.  The tap table sits in lane registers (lane t = tap t, read back with v_readlane) so the mask
+    // loop has no scalar-memory round trip per tap, and the two divisions per row are multiply-high by a reciprocal
+    // computed once (exact after one correction: see udiv_rcp).
+    const int tlane = lane < p.T ? lane : 0;
+    const int tap_dy = p.dy[tlane], tap_dx = p.dx[tlane], tap_dz = p.dz[tlane];
+    const unsigned rcp_w = 0xFFFFFFFFu / (unsigned)p.Wg + 1u, rcp_h = 0xFFFFFFFFu / (unsigned)p.Hg + 1u;
     RowInfoB ri[AP];
+    int riy[AP], rix[AP], rfz[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
-        ri[i].off = 0;
+        const unsigned mu = m < M ? (unsigned)m : 0u;
+        const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+        const int gx = (int)(mu - t * (unsigned)p.Wg);
+        const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+        const int gy = (int)(t - n_ * (unsigned)p.Hg);
+        const int n = (int)n_;
+        riy[i] = gy * p.in_stride;
+        rix[i] = gx * p.in_stride;
+        rfz[i] = p.Kfr == 1 ? 0 : n % p.Kfr;
+        ri[i].off = (int64_t)((n * p.Hi + riy[i]) * p.Wi + rix[i]) * p.Ci + lca;
         ri[i].mask = 0u;
-        if (m < M) {
-            const unsigned mu = (unsigned)m;
-            const unsigned t = mu / (unsigned)p.Wg;
-            const int gx = (int)(mu - t * (unsigned)p.Wg);
-            const unsigned n_ = t / (unsigned)p.Hg;
-            const int gy = (int)(t - n_ * (unsigned)p.Hg);
-            const int n = (int)n_;
-            const int iy0 = gy * p.in_stride, ix0 = gx * p.in_stride;
-            const int fz0 = n % p.Kfr;
-            ri[i].off = (int64_t)((n * p.Hi + iy0) * p.Wi + ix0) * p.Ci + lc8;
-            unsigned mk = 0u;
-            for (int t2 = 0; t2 < p.T; ++t2) {
-                const bool ok = (unsigned)(iy0 + p.dy[t2]) < (unsigned)p.Hi && (unsigned)(ix0 + p.dx[t2]) < (unsigned)p.Wi &&
-                                (unsigned)(fz0 + p.dz[t2]) < (unsigned)p.Kfr;
-                mk |= ok ? (1u << t2) : 0u;
-            }
-            ri[i].mask = mk;
+    }
+    for (int t2 = 0; t2 < p.T; ++t2) {
+        const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2),
+                  dz = __builtin_amdgcn_readlane(tap_dz, t2);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool ok = (unsigned)(riy[i] + dy) < (unsigned)p.Hi && (unsigned)(rix[i] + dx) < (unsigned)p.Wi &&
+                            (unsigned)(rfz[i] + dz) < (unsigned)p.Kfr;
+            ri[i].mask |= ok ? (1u << t2) : 0u;
         }
     }
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+        if ((int64_t)tile_m * BM + lrow + RPP * i >= M) ri[i].mask = 0u;
     int64_t boff[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -93,15 +133,41 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // PD register sets of gathered tiles + a branch-free steady-state loop: see k_conv_igemm (vd_conv.hip)
-    constexpr int PD = (WM * WN == 4 && TM * TN == 4) ? 2 : 3;
+    constexpr int PD = ((WM * WN == 4 && TM * TN == 4) || TM * TN == 8 || AP + BP > 8) ? 2 : 3;
     f32x4 ra[PD][AP], rb[PD][BP];
     int t_tap = 0, c0 = 0;
 
+    const int64_t tap_eo = (int64_t)((tap_dz * p.Hi + tap_dy) * p.Wi + tap_dx) * p.Ci;   // lane t: tap t
+    const int tap_eo_lo = (int)(tap_eo & 0xffffffffll), tap_eo_hi = (int)(tap_eo >> 32);
     auto tap_off = [&](int t) -> int64_t {
-        return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(tap_eo_lo, t);
+        const int hi = __builtin_amdgcn_readlane(tap_eo_hi, t);
+        return ((int64_t)hi << 32) | (int64_t)lo;
     };
     int64_t tap_soff = tap_off(0);
     auto gload = [&](f32x4 (&ra)[AP], f32x4 (&rb)[BP]) {
+        if constexpr (PAIR) {
+            // t_tap counts K-steps; taps 2*t_tap and 2*t_tap+1 (bit T of every mask is clear: an odd tail is zeros)
+            const int t0 = 2 * t_tap;
+            const int64_t so0 = tap_off(t0), so1 = tap_off(t0 + 1 < p.T ? t0 + 1 : t0);
+            const int64_t soff = ptap ? so1 : so0;
+            const int tl = t0 + ptap;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const bool ok = (ri[i].mask >> tl) & 1u;
+                const int64_t sel = ok ? ri[i].off + soff : zd_in;
+                ra[i] = *reinterpret_cast<const f32x4*>(in + sel);
+            }
+            const int koff = t_tap * KCH;
+            const bool kin = koff + lc8 < Ktot;
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int64_t sel = (boff[i] >= 0 && kin) ? boff[i] + koff : zd_w;
+                rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
+            }
+            ++t_tap;
+            return;
+        }
         const int64_t soff = tap_soff + c0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -149,10 +215,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
         }
     };
 
-    const int nks = p.T * (p.Ci / KCH);
+    const int nks = PAIR ? (p.T + 1) / 2 : p.T * (p.Ci / KCH);
+    STAMP(1);
     gload(ra[0], rb[0]);
+    STAMP(2);
     lstore(0, ra[0], rb[0]);
     __syncthreads();
+    STAMP(3);
     constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;
 #pragma unroll
     for (int d = 1; d < PD; ++d)
@@ -181,6 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
         }
     }
 
+    STAMP(4);
     // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs).  Per wave, one 32x32
     // accumulator tile at a time is transposed through a private LDS patch so that each lane owns 4 consecutive
     // columns of 4 rows: scale/shift/LeakyReLU/residual on 4-vectors and 8-byte (bf16 x4) or 16-byte (fp32 heads)
@@ -189,63 +259,112 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     constexpr int SLD = 36;
     float* stg = reinterpret_cast<float*>(smem_b) + wave * (32 * SLD);
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-    const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
-                        (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0)));
+    const bool has_aff = p.flags & VD_EPI_AFFINE, has_res = p.flags & VD_EPI_RESIDUAL, has_leaky = p.flags & VD_EPI_LEAKY;
+    const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) && (p.Co % 4 == 0) &&
+                        (!has_res || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0))) &&
+                        (!has_aff || (((uintptr_t)p.scale | (uintptr_t)p.shift) % 16 == 0));
+    if (vec_ok) {
+        // Straight-line path (every layer of the network): all scale/shift and residual loads are issued first, then
+        // each 32x32 accumulator block goes through the wave's LDS patch (LDS is in order within a wave, so the
+        // compiler barrier is all the synchronisation a block needs) and is stored without ever waiting on a store.
+        f32x4 sc[TN], sh[TN];
+        int colv[TN];
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
-        const int nvalid = p.Co - col;
-        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.flags & VD_EPI_AFFINE) {
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
+            colv[ni] = col < p.Co ? col : -1;
+            const int cc = col < p.Co ? col : 0;
+            sc[ni] = (has_aff && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + cc) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sh[ni] = (has_aff && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x4 rv[TM][TN][4];
+        if (has_res) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e < nvalid) {
-                    if (p.scale) sc[e] = p.scale[col + e];
-                    if (p.shift) sh[e] = p.shift[col + e];
-                }
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
+                        m = m < M ? m : M - 1;
+                        rv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(res + m * p.ldr + (colv[ni] < 0 ? 0 : colv[ni]));
+                    }
         }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int ni = 0; ni < TN; ++ni) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = erow + 8 * i;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SLD + ec4);
-                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
-                if (nvalid <= 0 || m >= M) continue;
-                if (p.flags & VD_EPI_AFFINE) {
+                for (int r = 0; r < 16; ++r)
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                f32x4 v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
-                }
-                if (p.flags & VD_EPI_LEAKY) {
+                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(stg + (erow + 8 * i) * SLD + ec4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-                }
-                if (nvalid >= 4 && vec_ok) {
-                    if (p.flags & VD_EPI_RESIDUAL) {
-                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + m * p.ldr + col);
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
+                    f32x4 t = v[i];
+                    if (has_aff) t = t * sc[ni] + sh[ni];
+                    if (has_leaky) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * p.slope;
                     }
-                    if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + col) = v;
-                    else {
-                        bf16x4 o;
+                    if (has_res) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + m * p.ldo + col) = o;
+                        for (int e = 0; e < 4; ++e) t[e] += (float)rv[mi][ni][i][e];
                     }
-                } else {
+                    if (m < M && colv[ni] >= 0) {
+                        if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + colv[ni]) = t;
+                        else {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)t[e];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + m * p.ldo + colv[ni]) = o;
+                        }
+                    }
+                }
+            }
+    } else {
+        // general path (odd leading dimensions / unaligned pointers): element-wise tails
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
+            const int nvalid = p.Co - col;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_aff) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nvalid) {
+                        if (p.scale) sc[e] = p.scale[col + e];
+                        if (p.shift) sh[e] = p.shift[col + e];
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = erow + 8 * i;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SLD + ec4);
+                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
+                    if (nvalid <= 0 || m >= M) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (e < nvalid) {
                             float t = v[e];
-                            if (p.flags & VD_EPI_RESIDUAL) t += (float)res[m * p.ldr + col + e];
+                            if (has_aff) t = t * sc[e] + sh[e];
+                            if (has_leaky) t = t > 0.f ? t : t * p.slope;
+                            if (has_res) t += (float)res[m * p.ldr + col + e];
                             if (OUT_F32) p.out[m * p.ldo + col + e] = t;
                             else reinterpret_cast<__bf16*>(p.out)[m * p.ldo + col + e] = (__bf16)t;
                         }
@@ -253,6 +372,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             }
         }
     }
+    STAMP(5);
+#if VD_STAMP
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[6] = wall_clock64();
+#endif
 }
 
 const float* zero_page_b() {
@@ -265,12 +388,12 @@ const float* zero_page_b() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool OUT_F32>
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false>
 void launch_b(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds = 2 * (BM + BN) * ROW_B;
     static bool attr_done = false;
-    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32>;
+    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
@@ -286,8 +409,17 @@ void launch_b(const vd_conv_desc& d, hipStream_t s) {
 template <bool OUT_F32>
 void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 7) tile = 2;
+    if (d.Ci == 32) {                                          // two taps per K-step; these layers have Co = 64
+        if (tile == 11) return launch_b<4, 1, 2, 2, OUT_F32, true>(d, s);
+        return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
+    }
+    if (tile <= 0 || tile > 12) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
     switch (tile) {
+        case 10: return launch_b<4, 2, 2, 1, OUT_F32>(d, s);  // 256 x 64, 8 waves of 64x32
+        case 11: return launch_b<4, 1, 2, 2, OUT_F32>(d, s);  // 256 x 64, 4 waves of 64x64
+        case 12: return launch_b<4, 1, 2, 1, OUT_F32>(d, s);  // 256 x 32, 4 waves of 64x32
+        case 8: return launch_b<2, 4, 4, 2, OUT_F32>(d, s);   // 256 x 256, 8 waves of 128x64 (1 block / CU)
+        case 9: return launch_b<4, 2, 2, 4, OUT_F32>(d, s);   // 256 x 256, 8 waves of 64x128 (1 block / CU)
         case 6: return launch_b<4, 2, 2, 2, OUT_F32>(d, s);   // 256 x 128, 8 waves of 64x64 (1 block / CU)
         case 7: return launch_b<2, 4, 2, 2, OUT_F32>(d, s);   // 128 x 256, 8 waves of 64x64 (1 block / CU)
         case 1: return launch_b<2, 2, 2, 2, OUT_F32>(d, s);   // 128 x 128, 4 waves of 64x64
@@ -345,7 +477,7 @@ extern "C" {
 
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
     VD_REQUIRE(d && d->in && d->wp && d->out, "vd_conv_igemm_bf16: null pointer");
-    VD_REQUIRE(d->Ci > 0 && d->Ci % 64 == 0, "vd_conv_igemm_bf16: Ci=%d must be a positive multiple of 64", d->Ci);
+    VD_REQUIRE(d->Ci == 32 || (d->Ci > 0 && d->Ci % 64 == 0), "vd_conv_igemm_bf16: Ci=%d must be 32 or a positive multiple of 64", d->Ci);
     VD_REQUIRE(d->T >= 1 && d->T <= VD_MAX_TAPS && d->Kfr >= 1 && d->N % d->Kfr == 0, "vd_conv_igemm_bf16: bad taps");
     VD_REQUIRE(d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg,
                "vd_conv_igemm_bf16: forward geometry only");
@@ -361,6 +493,12 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
     VD_CHECK_LAUNCH("vd_conv_igemm_bf16");
     return VD_OK;
 }
+
+#if VD_STAMP
+int vd_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T, void* stream) {
     VD_REQUIRE(wp_f32 && wp_bf16 && Co > 0 && Co_pad >= Co && Ci > 0 && Ci_pad >= Ci && T > 0, "vd_pack_weight_bf16: bad args");

@@ -488,6 +488,8 @@ class YOLOV3(object):
         self._programs = {}
         self._fold_dirty = True
         self._dgrad_dirty = True
+        self._pack_stream = None
+        self._pack_event = None
         self._graph_cache = {}
         self.use_graphs = False
         import os as _os
@@ -843,7 +845,8 @@ class YOLOV3(object):
     def _build_infer_bf16(self, B, H, W):
         dev = self.device
         lib = L.load()
-        cp = lambda c: round_up(c, 64)
+        # channel runs of 64 (one 128-byte K-step); a 32-channel map stays unpadded (two taps per K-step, vd_conv_bf16.hip)
+        cp = lambda c: 32 if c == 32 else round_up(c, 64)
         bufs = {'in': torch.empty(B, 3, H, W, device=dev)}
         for name, (c, div, ld, fr) in self.tensors.items():
             if name == 'in':
@@ -851,7 +854,7 @@ class YOLOV3(object):
             if name in self.head_names:
                 bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
             else:
-                # zeros: the stem kernel writes 32 of its 64 padded channels and never touches the rest
+                # zeros: padded channels are never written
                 bufs[name] = torch.zeros(B, H // div, W // div, cp(c), dtype=torch.bfloat16, device=dev)
         prog = Program()
         packs = []
@@ -941,7 +944,9 @@ class YOLOV3(object):
             key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.flags, of32)
             if key not in _TUNE_CACHE:
                 best, best_t = 2, None
-                for c in (1, 2, 3, 4, 5, 6, 7):
+                verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
+                for c in ((10, 11) if d.Ci == 32 else (12, 10, 11) if d.Co <= 32 else (10, 11, 2, 3, 4, 5) if d.Co <= 64
+                          else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ())):
                     d.tile = c
                     L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -951,6 +956,9 @@ class YOLOV3(object):
                     e1.record()
                     e1.synchronize()
                     t = e0.elapsed_time(e1)
+                    if verbose:
+                        fl = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
+                        print("bf16 tune %s tile %d: %.3f ms %.0f TF" % (key[1:10], c, t / 3, fl), flush=True)
                     if best_t is None or t < best_t:
                         best, best_t = c, t
                 _TUNE_CACHE[key] = best
@@ -1416,12 +1424,28 @@ class YOLOV3(object):
         self._ones(c)
         return self._const[1]
 
-    def _refresh_dgrad(self, tp):
+    def _refresh_dgrad(self, tp, overlap=False):
+        """Re-pack the data-gradient weight layout after the weights moved. With overlap=True (start of a training
+        step) the 72 small pack launches run on a side stream beside the forward pass; backward() waits on the event."""
         if not self._dgrad_dirty:
             return
-        for n, plan, wpk in tp['dgrad_packs']:
-            ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
-                                  tap_ids=plan['tap_ids'], src_packed=True)
+        ev = None
+        if overlap and self.overlap_wgrad:
+            if self._pack_stream is None:
+                self._pack_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._pack_stream.wait_stream(cur)          # the optimiser's weight update is on the main stream
+            with torch.cuda.stream(self._pack_stream):
+                for n, plan, wpk in tp['dgrad_packs']:
+                    ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
+                                          tap_ids=plan['tap_ids'], src_packed=True)
+                ev = torch.cuda.Event()
+                ev.record(self._pack_stream)
+        else:
+            for n, plan, wpk in tp['dgrad_packs']:
+                ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
+                                      tap_ids=plan['tap_ids'], src_packed=True)
+        self._pack_event = ev
         self._dgrad_dirty = False
 
     @staticmethod
@@ -1455,6 +1479,7 @@ class YOLOV3(object):
         s['wgt'].value, s['cls'].value = wgt.data_ptr(), cls.data_ptr()
         s['smooth'].value = 1 if self._label_smooth else 0
         self._stage_inputs(tp['bufs'], x)
+        self._refresh_dgrad(tp, overlap=True)
         self._run_segments(tp['fwd'])
         self._fold_dirty = True            # running stats moved
         self._last_train = tp
@@ -1473,7 +1498,10 @@ class YOLOV3(object):
         """autograd.backward(sum_losses) (train_yolov3.py:631): gradient of the sum of all four losses over the
         local batch wrt every parameter, written into the gradient arena."""
         tp = self._last_train
-        self._refresh_dgrad(tp)
+        self._refresh_dgrad(tp)            # only if the weights moved between the forward and this call
+        if self._pack_event is not None:
+            torch.cuda.current_stream().wait_event(self._pack_event)
+            self._pack_event = None
         self._run_segments(tp['bwd'])
 
     # ------------------------------------------------------------------ call protocol
