@@ -44,6 +44,21 @@ constexpr int LDS_LD = 36;
 // a resident page of zeros: the load target of padded / out-of-window rows (see the tap_off select in k_conv_igemm)
 __device__ __attribute__((aligned(64))) float g_zero_page[64];
 
+// developer build (-DVD_STAMP=1, tools/stamp_conv.py): wave 0 of one mid-grid workgroup records s_memtime at the
+// phase boundaries of k_conv_igemm
+#ifndef VD_STAMP
+#define VD_STAMP 0
+#endif
+#if VD_STAMP
+__device__ unsigned long long g_stamps_f32[16];
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps_f32[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 // intra-wave LDS hand-off: LDS ops of one wave execute in order, so only the compiler must be kept from
 // reordering the accesses (no instruction is generated)
 #define WAVE_SYNC()                                              \
@@ -86,6 +101,13 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& h, uint2& m, uint2&
         hh[q] = hp; mm[q] = mp; ll[q] = pk_bf16(s0, s1);
     }
     h = make_uint2(hh[0], hh[1]); m = make_uint2(mm[0], mm[1]); l = make_uint2(ll[0], ll[1]);
+}
+
+// n / d for d >= 1 with rcp = 0xFFFFFFFF / d + 1: the multiply-high overshoots the quotient by at most one
+__device__ __forceinline__ unsigned udiv_rcp(unsigned n, unsigned d, unsigned rcp) {
+    unsigned q = d == 1u ? n : __umulhi(n, rcp);
+    q -= (q * d > n) ? 1u : 0u;
+    return q;
 }
 
 struct RowInfo {
@@ -137,31 +159,45 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     const int lrow = tid >> 3;
     const int lc4 = (tid & 7) * 4;
 
+    STAMP(0);
+    // Row geometry (M < 2^31, checked on the host).  The tap table sits in lane registers (lane t = tap t, read back
+    // with v_readlane), so neither the mask loop here nor the K loop pays a scalar-memory round trip per tap, and the
+    // two divisions per row are a multiply-high by a reciprocal computed once (udiv_rcp).  The per-tap loop used to
+    // cost 12k cycles of a workgroup's life: a quarter of the whole 32->64 3x3 layers.
+    const int tlane = lane < p.T ? lane : 0;
+    const int tap_dy = p.dy[tlane], tap_dx = p.dx[tlane], tap_dz = p.dz[tlane];
+    const unsigned rcp_w = 0xFFFFFFFFu / (unsigned)p.Wg + 1u, rcp_h = 0xFFFFFFFFu / (unsigned)p.Hg + 1u;
     RowInfo ri[AP];
+    {
+        int riy[AP], rix[AP], rfz[AP];
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
-        ri[i].off = 0;
-        ri[i].mask = 0u;
-        if (m < M) {
-            // M < 2^31 (checked on the host): 32-bit divisions instead of the 64-bit slow path
-            const unsigned mu = (unsigned)m;
-            const unsigned t = mu / (unsigned)p.Wg;
+        for (int i = 0; i < AP; ++i) {
+            const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
+            const unsigned mu = m < M ? (unsigned)m : 0u;
+            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
             const int gx = (int)(mu - t * (unsigned)p.Wg);
-            const unsigned n_ = t / (unsigned)p.Hg;
+            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
             const int gy = (int)(t - n_ * (unsigned)p.Hg);
             const int n = (int)n_;
-            const int iy0 = gy * p.in_stride, ix0 = gx * p.in_stride;
-            const int fz0 = n % p.Kfr;
-            ri[i].off = (int64_t)((n * p.Hi + iy0) * p.Wi + ix0) * p.Ci + lc4;
-            unsigned mk = 0u;
-            for (int t2 = 0; t2 < p.T; ++t2) {
-                const bool ok = (unsigned)(iy0 + p.dy[t2]) < (unsigned)p.Hi && (unsigned)(ix0 + p.dx[t2]) < (unsigned)p.Wi &&
-                                (unsigned)(fz0 + p.dz[t2]) < (unsigned)p.Kfr;
-                mk |= ok ? (1u << t2) : 0u;
-            }
-            ri[i].mask = mk;
+            riy[i] = gy * p.in_stride;
+            rix[i] = gx * p.in_stride;
+            rfz[i] = p.Kfr == 1 ? 0 : n % p.Kfr;
+            ri[i].off = (int64_t)((n * p.Hi + riy[i]) * p.Wi + rix[i]) * p.Ci + lc4;
+            ri[i].mask = 0u;
         }
+        for (int t2 = 0; t2 < p.T; ++t2) {
+            const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2),
+                      dz = __builtin_amdgcn_readlane(tap_dz, t2);
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const bool ok = (unsigned)(riy[i] + dy) < (unsigned)p.Hi && (unsigned)(rix[i] + dx) < (unsigned)p.Wi &&
+                                (unsigned)(rfz[i] + dz) < (unsigned)p.Kfr;
+                ri[i].mask |= ok ? (1u << t2) : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            if ((int64_t)tile_m * BM + lrow + RPP * i >= M) ri[i].mask = 0u;
     }
     int64_t boff[BP];
 #pragma unroll
@@ -185,8 +221,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 
     // tap part of the wave-uniform source offset: refreshed only when the tap changes (every Ci/32 K-steps), so the
     // scalar loads of dy/dx/dz and their s_waitcnt leave the per-step critical path
+    const int64_t tap_eo = (int64_t)((tap_dz * p.Hi + tap_dy) * p.Wi + tap_dx) * p.Ci;   // lane t: tap t
+    const int tap_eo_lo = (int)(tap_eo & 0xffffffffll), tap_eo_hi = (int)(tap_eo >> 32);
     auto tap_off = [&](int t) -> int64_t {
-        return (int64_t)((p.dz[t] * p.Hi + p.dy[t]) * p.Wi + p.dx[t]) * p.Ci;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(tap_eo_lo, t);
+        const int hi = __builtin_amdgcn_readlane(tap_eo_hi, t);
+        return ((int64_t)hi << 32) | (int64_t)lo;
     };
     int64_t tap_soff = tap_off(0);
     auto gload = [&](f32x4 (&ra)[AP], f32x4 (&rb)[BP]) {
@@ -377,9 +417,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     };
 
     const int nks = p.T * (p.Ci / BK);
+    STAMP(1);
     gload(ra[0], rb[0]);
+    STAMP(2);
     lstore(0, ra[0], rb[0]);
     __syncthreads();
+    STAMP(3);
     // timing probes (compile with -DVD_PROBE=bits; results are garbage): bit0 skip the global loads, bit1 skip the
     // LDS stores (and the operand split), bit2 skip the per-step barrier
     constexpr bool ld = !(VD_PROBE & 1), st = !(VD_PROBE & 2), bar = !(VD_PROBE & 4);
@@ -426,6 +469,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         }
     }
 
+    STAMP(4);
     // ---- epilogue -----------------------------------------------------------------------
     // The C/D layout has a column per lane and rows across registers: stored directly, one instruction writes two
     // 128-B row segments of 4 B per lane.  Each wave instead transposes one 32x32 accumulator tile at a time through
@@ -446,6 +490,105 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     // float4 path: rows 16-B aligned (wave-uniform; every tensor of the model qualifies, odd pitches fall back)
     const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
                         (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 16 == 0)));
+    const bool has_aff = p.flags & VD_EPI_AFFINE, has_leaky = p.flags & VD_EPI_LEAKY, has_res = p.flags & VD_EPI_RESIDUAL;
+    bool fast = vec_ok && (p.Co % 4 == 0) && (!has_aff || (((uintptr_t)p.scale | (uintptr_t)p.shift) % 16 == 0));
+    if (BS) fast = fast && (!bstat || (((uintptr_t)p.bs_z | (uintptr_t)p.bs_scale | (uintptr_t)p.bs_shift |
+                                        (uintptr_t)p.bs_mean | (uintptr_t)p.bs_invstd) % 16 == 0));
+    if (fast) {
+        // Straight-line path (every launch of the network).  Per-column constants are loaded once up front; the
+        // residual / BatchNorm-input rows of block b+1 are requested before block b goes through the LDS patch, so
+        // their latency hides behind it; nothing ever waits for a store.  (The element-wise path below waited for
+        // every load and store round trip in turn: 8-20k cycles per workgroup.)
+        constexpr int NB = TM * TN;
+        f32x4 sc[TN], sh[TN], qsc[BS ? TN : 1], qsh[BS ? TN : 1], qmu[BS ? TN : 1], qis[BS ? TN : 1];
+        int colv[TN];
+        const f32x4 ones = {1.f, 1.f, 1.f, 1.f}, zeros = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
+            colv[ni] = col < p.Co ? col : -1;
+            const int cc = col < p.Co ? col : 0;
+            sc[ni] = (has_aff && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + cc) : ones;
+            sh[ni] = (has_aff && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + cc) : zeros;
+            if (BS) {
+                qsc[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_scale + cc) : zeros;
+                qsh[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_shift + cc) : zeros;
+                qmu[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_mean + cc) : zeros;
+                qis[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_invstd + cc) : zeros;
+            }
+        }
+        // two register slots (block b+1 in flight under block b) except on the 8-wave fp32-MFMA tiles, which live
+        // inside 128 VGPRs: there block b's rows are requested just before its own pass through LDS
+        constexpr int NSL = (!SP && WM * WN == 8) ? 1 : 2;
+        f32x4 rres[NSL][4], rz[BS ? NSL : 1][4];
+        int64_t ropix[NSL][4];
+        auto issue = [&](int mi, int ni, f32x4 (&rr)[4], f32x4 (&zz)[4], int64_t (&op)[4]) {
+            const int cc = colv[ni] < 0 ? 0 : colv[ni];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
+                m = m < M ? m : M - 1;
+                int64_t opix = m;
+                if (!direct) {
+                    const unsigned mu = (unsigned)m;
+                    const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+                    const int gx = (int)(mu - t * (unsigned)p.Wg);
+                    const unsigned n = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+                    const int gy = (int)(t - n * (unsigned)p.Hg);
+                    opix = ((int64_t)n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
+                }
+                op[i] = opix;
+                if (has_res) rr[i] = *reinterpret_cast<const f32x4*>(p.residual + opix * p.ldr + cc);
+                if (BS && bstat) zz[i] = *reinterpret_cast<const f32x4*>(p.bs_z + opix * p.ldo + cc);
+            }
+        };
+        if (NSL == 2) issue(0, 0, rres[0], rz[0], ropix[0]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int mi = b % TM, ni = b / TM;
+            constexpr int S1 = NSL - 1;
+            if (NSL == 1) issue(mi, ni, rres[0], rz[0], ropix[0]);
+            else if (b + 1 < NB)
+                issue((b + 1) % TM, (b + 1) / TM, rres[(b + 1) & S1], rz[BS ? ((b + 1) & S1) : 0], ropix[(b + 1) & S1]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = M16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int scol = M16 ? 16 * ((r >> 2) & 1) + (lane & 15) : (lane & 31);
+                stg[srow * LDS_LD + scol] = acc[mi][ni][r];
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(stg + (erow + 8 * i) * LDS_LD + ec4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
+                const bool ok = m < M && colv[ni] >= 0;
+                f32x4 t = v[i];
+                if (has_aff) t = t * sc[ni] + sh[ni];
+                if (has_leaky) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * p.slope;
+                }
+                if (has_res) t += rres[b & S1][i];
+                if (ok) *reinterpret_cast<f32x4*>(p.out + ropix[b & S1][i] * p.ldo + colv[ni]) = t;
+                if (BS && bstat) {
+                    const f32x4 z = rz[BS ? (b & S1) : 0][i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = z[e] * qsc[ni][e] + qsh[ni][e];
+                        float g = u > 0.f ? t[e] : t[e] * p.bs_slope;
+                        g = ok ? g : 0.f;
+                        bs1[ni][e] += g;
+                        bs2[ni][e] += g * (z[e] - qmu[ni][e]) * qis[ni][e];
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
@@ -537,6 +680,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         }
     }
 
+    }
+    STAMP(5);
     // ---- fused BatchNorm backward reductions: a lane holds 4 columns x (4 rows x TM tiles); fold the 8 row groups of
     // the wave (lane bits 3..5), then the WM waves that share the columns, one writer per (tile_m, column)
     if (bstat) {
@@ -642,6 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             }
         }
     }
+    STAMP(6);
 }
 
 const float* zero_page() {
@@ -1223,6 +1369,12 @@ int check_taps(int T, const int32_t* dy, const int32_t* dx, int Hi, int Wi) {
 }  // namespace
 
 extern "C" {
+
+#if VD_STAMP
+int vd_debug_stamps_f32(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_f32), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(d && d->in && d->wp && d->out, "vd_conv_igemm: null pointer");
