@@ -264,7 +264,8 @@ def main():
         # command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
         try:
             if train and B == 64 and S == 416 and C == 80:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01f_train_b64_416_pmc_traffic.json")))
+                import glob
+                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_b64_416_pmc_traffic.json")))[-1]))
                 roof["traffic"] = round(pm["k_conv_igemm"]["hbm_mb_corrected"], 1)
                 roof["traffic_unit"] = ("MB per launch leaving the L2s (2 x FETCH_SIZE + WRITE_SIZE over the final step's launches; "
                                         "MALL hits count as fetches, so this bounds HBM bytes from above)")

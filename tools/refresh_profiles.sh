@@ -1,0 +1,25 @@
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01h; mkdir -p $O
+cd $R
+python bench.py > $O/train_bench.json 2> $O/train_bench.err
+echo "train done"; cut -c1-160 $O/train_bench.json
+python bench.py --mode detect --no-cpu-baseline > $O/detect_bench.json 2> $O/detect.err
+python bench.py --mode detect --dtype bf16 --no-cpu-baseline > $O/detect_bf16_bench.json 2> $O/detect_bf16.err
+echo "detect done"; cut -c1-160 $O/detect_bench.json; cut -c1-160 $O/detect_bf16_bench.json
+python bench.py --window 3 --batch 16 --classes 30 --no-cpu-baseline > $O/train_k3_bench.json 2> $O/k3.err
+python bench.py --dtype bf16 --no-cpu-baseline > $O/train_bf16products_bench.json 2> $O/bf16p.err
+echo "k3/bf16p done"; cut -c1-160 $O/train_k3_bench.json; cut -c1-160 $O/train_bf16products_bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train.json 2> $O/prof_train.err
+echo "prof train done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_detect_bf16 -- python3 $R/bench.py --mode detect --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_detect_bf16.json 2> $O/prof_detect_bf16.err
+echo "prof detect done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+echo "pmc fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
+echo "pmc write done"
+cd $R
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last k_conv_igemm=163,k_conv_wgrad=74 | tail -3
+# keep only the small summaries
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
+du -sh $O
