@@ -24,7 +24,7 @@ _BF16_CASES = [(t, sh) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9)
                for sh in [(2, 64, 13, 11, 128, 3, 1, 1), (3, 128, 8, 8, 192, 1, 1, 0), (2, 64, 17, 15, 64, 3, 2, 1)]]
 # narrow-output tiles (Co = 64 / 32) and the two-taps-per-K-step layout of 32-channel inputs (3x3: odd tap count ->
 # half-empty last K-step; 1x1: a single half-empty K-step; stride 2)
-_BF16_CASES += [(t, sh) for t in (10, 11) for sh in [(2, 64, 17, 15, 64, 3, 1, 1), (2, 128, 9, 9, 64, 1, 1, 0),
+_BF16_CASES += [(t, sh) for t in (10, 11, 13) for sh in [(2, 64, 17, 15, 64, 3, 1, 1), (2, 128, 9, 9, 64, 1, 1, 0),
                                                       (2, 32, 19, 21, 64, 3, 1, 1), (2, 32, 18, 20, 64, 3, 2, 1),
                                                       (1, 32, 9, 9, 64, 1, 1, 0), (3, 32, 40, 24, 40, 3, 1, 1)]]
 _BF16_CASES += [(12, (2, 64, 21, 19, 32, 1, 1, 0)), (12, (2, 64, 12, 12, 24, 3, 1, 1)), (0, (2, 64, 21, 19, 32, 1, 1, 0)),

@@ -411,13 +411,15 @@ void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
     int tile = d.tile;
     if (d.Ci == 32) {                                          // two taps per K-step; these layers have Co = 64
         if (tile == 11) return launch_b<4, 1, 2, 2, OUT_F32, true>(d, s);
+        if (tile == 13) return launch_b<2, 2, 2, 1, OUT_F32, true>(d, s);
         return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
     }
-    if (tile <= 0 || tile > 12) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
+    if (tile <= 0 || tile > 13) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
     switch (tile) {
         case 10: return launch_b<4, 2, 2, 1, OUT_F32>(d, s);  // 256 x 64, 8 waves of 64x32
         case 11: return launch_b<4, 1, 2, 2, OUT_F32>(d, s);  // 256 x 64, 4 waves of 64x64
         case 12: return launch_b<4, 1, 2, 1, OUT_F32>(d, s);  // 256 x 32, 4 waves of 64x32
+        case 13: return launch_b<2, 2, 2, 1, OUT_F32>(d, s);  // 128 x 64, 4 waves of 64x32 (two blocks / CU)
         case 8: return launch_b<2, 4, 4, 2, OUT_F32>(d, s);   // 256 x 256, 8 waves of 128x64 (1 block / CU)
         case 9: return launch_b<4, 2, 2, 4, OUT_F32>(d, s);   // 256 x 256, 8 waves of 64x128 (1 block / CU)
         case 6: return launch_b<4, 2, 2, 2, OUT_F32>(d, s);   // 256 x 128, 8 waves of 64x64 (1 block / CU)

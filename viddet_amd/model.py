@@ -945,7 +945,7 @@ class YOLOV3(object):
             if key not in _TUNE_CACHE:
                 best, best_t = 2, None
                 verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
-                for c in ((10, 11) if d.Ci == 32 else (12, 10, 11) if d.Co <= 32 else (10, 11, 2, 3, 4, 5) if d.Co <= 64
+                for c in ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
                           else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ())):
                     d.tile = c
                     L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
