@@ -180,6 +180,8 @@ def autotune_desc(d, reps=3):
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
+            if os.environ.get("VD_TUNE_VERBOSE") == "1":
+                print("igemm tune %s math %d tile %d: %.4f ms" % (key[1:11], fl, c, t / reps), flush=True)
             if best_t is None or t < best_t:
                 best, best_t = (fl, c), t
     d.flags, d.tile = base | best[0], best[1]
@@ -214,6 +216,8 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
+            if os.environ.get("VD_TUNE_VERBOSE") == "1":
+                print("wgrad tune %s flags %d: %.4f ms" % (key[1:11], fl, t / reps), flush=True)
             if best_t is None or t < best_t:
                 best, best_t = fl, t
         _TUNE_CACHE[key] = best
