@@ -168,22 +168,28 @@ def autotune_desc(d, reps=3):
         d.flags = base | fl
         return
     cands = _tile_candidates(d, math)
-    best, best_t = cands[0], None
+    best = cands[0]
     if len(cands) > 1:
-        for fl, c in cands:
+        def time_of(fl, c, n):
             d.flags, d.tile = base | fl, c
             L.check(lib.vd_conv_igemm(C.byref(d), s), 'vd_conv_igemm/tune')
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
+            for _ in range(n):
                 lib.vd_conv_igemm(C.byref(d), s)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1)
+            t = e0.elapsed_time(e1) / n
             if os.environ.get("VD_TUNE_VERBOSE") == "1":
-                print("igemm tune %s math %d tile %d: %.4f ms" % (key[1:11], fl, c, t / reps), flush=True)
-            if best_t is None or t < best_t:
-                best, best_t = (fl, c), t
+                print("igemm tune %s math %d tile %d: %.4f ms (%d launches)" % (key[1:11], fl, c, t, n), flush=True)
+            return t
+        ranked = sorted((time_of(fl, c, reps), (fl, c)) for fl, c in cands)
+        best = ranked[0][1]
+        # candidates within 4 % of the fastest are re-timed with more launches: the first pass is 3 launches each, and
+        # launch-to-launch noise under the power limit is of that order
+        close = [fc for t, fc in ranked if t <= 1.04 * ranked[0][0]][:3]
+        if len(close) > 1:
+            best = min((time_of(fl, c, 3 * reps), (fl, c)) for fl, c in close)[1]
     d.flags, d.tile = base | best[0], best[1]
     _TUNE_CACHE[key] = best
 
