@@ -509,7 +509,10 @@ class YOLOV3(object):
         self.bucketed_allreduce = _os.environ.get('VD_BUCKETED', '1') != '0'
         self.alias_skip_grad = _os.environ.get('VD_ALIAS_SKIP', '1') != '0'    # skip gradients by alias, not by copy
         self.fuse_bn_bwd = _os.environ.get('VD_FUSE_BWD', '1') != '0'          # BN backward reductions in the dgrad epilogue
-        self.bucket_elems = 16 << 20   # 64 MB of fp32 gradients per all-reduce
+        # fp32 gradients per all-reduce.  The tail bucket (everything below stage 4: ~15 M parameters, the layers whose
+        # gradients come last) closes with the stem and is the one collective nothing overlaps, so buckets are kept at
+        # 32 MB: large enough for the ring to reach its bandwidth, small enough that the exposed tail stays ~30 MB.
+        self.bucket_elems = int(float(_os.environ.get('VD_BUCKET_MB', '32')) * (1 << 18))
         self._pending_reduces = []
         self._reduced_from = 1 << 62
         self._bucket_group = None      # second communicator for the gradient buckets when SyncBN collectives exist
@@ -1082,7 +1085,7 @@ class YOLOV3(object):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.process_group)
             # With SyncBN the statistics all-reduces sit on the critical path of backward; on one communicator they
-            # would queue behind a 64 MB gradient bucket in flight (one RCCL stream per communicator).  The buckets get
+            # would queue behind a gradient bucket in flight (one RCCL stream per communicator).  The buckets get
             # their own communicator (new_group is collective: every rank builds its training plan at the same point).
             if (world > 1 and self.syncbn_scope and self.bucketed_allreduce and self._bucket_group is None
                     and self.process_group is None):
@@ -1355,7 +1358,7 @@ class YOLOV3(object):
             else:
                 seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
             # bucketed gradient all-reduce, overlapped with the rest of the backward pass: weight gradients complete
-            # in reverse arena order on the stream that runs the wgrad GEMMs, so every time ~64 MB of the arena tail
+            # in reverse arena order on the stream that runs the wgrad GEMMs, so every time a bucket (~32 MB) of the arena tail
             # is final an async all-reduce of that contiguous range is queued behind them (RCCL syncs with that
             # stream); allreduce_grads() later waits for the handles and reduces the small gamma/beta/bias range.
             bucket_acc[0] += n.w_numel
@@ -1560,7 +1563,7 @@ class YOLOV3(object):
 
     def allreduce_grads(self):
         """kvstore-'local' replacement (train_yolov3.py:530): RCCL sum all-reduce of the flat gradient arena.
-        With bucketing (default) the conv-weight range was already queued in ~64 MB pieces during backward();
+        With bucketing (default) the conv-weight range was already queued in ~32 MB pieces during backward();
         here the handles are awaited and the remaining small range (gamma, beta, head bias) is reduced."""
         if not self._dp_active():
             return
