@@ -32,10 +32,12 @@ def test_param_roundtrip_and_count():
         assert maxdiff(net.collect_params()[k].data().cpu().numpy(), P[k]) == 0.0, k
 
 
-@pytest.mark.parametrize("cfg", [dict(b=2, c=4, size=64, seed=3), dict(b=1, c=20, size=96, seed=4)])
+@pytest.mark.parametrize("cfg", [dict(b=2, c=4, size=64, seed=3), dict(b=1, c=20, size=96, seed=4),
+                                 dict(b=1, c=20, size=608, seed=5, obj_bias=-4.0)])     # one full 608x608 frame (objectness
+                                                                                      # prior low enough for the candidate cap)
 def test_inference_matches_oracle(cfg):
     b, c, size = cfg["b"], cfg["c"], cfg["size"]
-    net, P = _mk_net(c, cfg["seed"], obj_bias=-1.0)
+    net, P = _mk_net(c, cfg["seed"], obj_bias=cfg.get("obj_bias", -1.0))
     rng = np.random.default_rng(cfg["seed"])
     x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
     onet = ON.Net(P, c)
@@ -88,8 +90,9 @@ def _targets(rng, b, c, size, m):
     return gt, Y.prefetch_targets(size, size, grids, gt, ids, c)
 
 
-def test_training_step_matches_oracle():
-    b, c, size, m = 2, 4, 64, 3
+@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6)])     # the second: one 416x416 voc frame, full-size grids
+def test_training_step_matches_oracle(cfg):
+    b, c, size, m = cfg
     net, P = _mk_net(c, 6, obj_bias=-1.0)
     rng = np.random.default_rng(6)
     x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
