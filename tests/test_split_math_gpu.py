@@ -40,6 +40,29 @@ def test_split_fwd_every_tile(tile, shape):
     assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL
 
 
+@pytest.mark.parametrize("tile", [9, 10])
+@pytest.mark.parametrize("shape", [(2, 64, 23, 19, 32, 1, 1, 0), (3, 64, 17, 15, 32, 3, 1, 1), (2, 96, 20, 22, 24, 3, 2, 1),
+                                   (5, 32, 9, 31, 32, 3, 1, 1)])
+def test_split_fwd_32_column_tiles(tile, shape):
+    """Tiles 9 / 10: 256 x 32 (8 waves of 32x32; half of the loader lanes carry no weight row) for outputs of up to 32
+    channels - the data gradients of the first-stage 3x3 convs and the 1x1 64->32 forward."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = shape
+    rng, x, wt = _mk(n, ci, h, w, co, k, 270 + tile)
+    res = rng.standard_normal((n, co, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1))
+    sc, sh = rng.uniform(0.5, 1.5, co), rng.standard_normal(co)
+    u = R.conv2d(x, wt, s, p) * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = np.where(u > 0, u, 0.1 * u) + res
+    co_pad = ops.round_up(co, 32)
+    out = torch.full((n, ref.shape[2], ref.shape[3], co_pad), 7.0, device="cuda")
+    scd, shd = torch.zeros(co_pad, device="cuda"), torch.zeros(co_pad, device="cuda")
+    scd[:co], shd[:co] = dev(sc), dev(sh)
+    ops.conv_fwd(nchw_to_dev_nhwc(x), _packed(wt, co_pad), out, k=k, stride=s, pad=p, Co=co_pad, ldo=co_pad,
+                 scale=scd, shift=shd, leaky=True, residual=nchw_to_dev_nhwc(res, co_pad), tile=tile, split=True)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(out, co), ref) < TOL
+
+
 @pytest.mark.parametrize("case", [(2, 64, 12, 12, 128, 3, 1, 1), (2, 32, 20, 20, 64, 3, 2, 1), (1, 64, 15, 17, 128, 3, 2, 1),
                                   (3, 256, 13, 13, 128, 1, 1, 0), (2, 96, 9, 9, 75, 1, 1, 0)])
 def test_split_dgrad(case):

@@ -139,9 +139,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
     constexpr int RPP = NT / 8;               // tile rows one pass of float4 lanes covers
-    constexpr int AP = BM / RPP, BP = BN / RPP;
+    // BN < RPP (the 32-column split tile: 8 waves, 64 loader rows per pass): one weight pass in which only the lanes of
+    // rows < BN take part - the others request the zero page and skip the LDS store (BHALF)
+    constexpr bool BHALF = BN < RPP;
+    constexpr int AP = BM / RPP, BP = BHALF ? 1 : BN / RPP;
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile vs loader");
+    static_assert(BM % RPP == 0 && (BHALF || BN % RPP == 0), "tile vs loader");
+    static_assert(!BHALF || SP, "the half-populated weight pass exists for the split-math tiles");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                        // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
         const int n = tile_n * BN + lrow + RPP * i;
-        boff[i] = (n < p.Co) ? (int64_t)n * Ktot + lc4 : (int64_t)-1;       // -1: row beyond Co reads zeros
+        boff[i] = (n < p.Co && (!BHALF || lrow < BN)) ? (int64_t)n * Ktot + lc4 : (int64_t)-1;   // -1: reads zeros
     }
 
     f32x16 acc[TM][TN];
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             }
 #pragma unroll
             for (int i = 0; i < BP; ++i) {
+                if (BHALF && lrow >= BN) break;           // wave-uniform: these lanes hold no weight row
                 uint2 h, m, l;
                 char* r = b3 + (lrow + RPP * i) * SP_ROWB;
                 if (NPL == 3) {
@@ -854,10 +859,10 @@ int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
 // double-buffered 256x128 stage fill the 160 KB of LDS)
 int igemm_split_resolve_tile(const vd_conv_desc& d) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 8) tile = d.Co <= 64 ? 3 : 1;
+    if (tile <= 0 || tile > 10) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
     return tile;
 }
-int igemm_split_tile_bm(int tile) { return (((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128; }
+int igemm_split_tile_bm(int tile) { return (tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128; }
 
 template <bool XF>
 int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
@@ -870,7 +875,10 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
         case 5: return launch_igemm<4, 2, 2, 2, XF, true, true>(d, s);
         case 6: return launch_igemm<4, 2, 1, 2, XF, true, true>(d, s);
         case 7: return launch_igemm<4, 2, 2, 1, XF, true, true>(d, s);
-        default: return launch_igemm<4, 2, 1, 1, XF, true, true>(d, s);
+        case 8: return launch_igemm<4, 2, 1, 1, XF, true, true>(d, s);
+        // 9, 10: 256 x 32 (8 waves of 32x32) for the 32-channel outputs of the first stage, both MFMA shapes
+        case 9: return launch_igemm<8, 1, 1, 1, XF, true>(d, s);
+        default: return launch_igemm<8, 1, 1, 1, XF, true, true>(d, s);
     }
 }
 

@@ -140,12 +140,12 @@ def _tile_candidates(d, math):
             cands += [(0, t) for t in (1, 2, 3, 4, 5)]
     if math in ("split", "auto", "bf16"):
         fl = L.MATH_BF16 if math == "bf16" else L.MATH_SPLIT
-        if d.Co <= 64:           # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
+        if d.Co <= 32:           # 256 x 32 tiles (9: 32x32x16 MFMA, 10: 16x16x32)
+            cands += [(fl, t) for t in (9, 10)]
+        elif d.Co <= 64:         # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
             cands += [(fl, t) for t in (3, 4, 7, 8)]
         else:
             cands += [(fl, t) for t in (1, 2, 3, 4, 5, 6, 7, 8)]
-        if math == "bf16" and d.Co <= 32:          # nothing narrower than 64 columns in the split tiles
-            cands = [(0, 7)]
     return cands
 
 
@@ -157,7 +157,7 @@ def autotune_desc(d, reps=3):
     math = fp32_math()
     base = d.flags & ~(L.MATH_SPLIT | L.MATH_BF16)
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
-        d.flags = base | (L.MATH_SPLIT if math == "split" else (L.MATH_BF16 if math == "bf16" and d.Co > 32 else 0))
+        d.flags = base | (L.MATH_SPLIT if math == "split" else (L.MATH_BF16 if math == "bf16" else 0))
         return
     lib = L.load()
     s = L.stream_ptr()
