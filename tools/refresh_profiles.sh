@@ -21,5 +21,10 @@ echo "pmc write done"
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last k_conv_igemm=163,k_conv_wgrad=74 | tail -3
 # keep only the small summaries
+python tools/last_step_kernels.py $O/prof_train $O/train_last_step_kernels.json
+# the same step with the weight-gradient GEMMs on the main stream: every launch runs alone, so its rocprof duration is
+# comparable with bench.py's per-launch event timing (roofline.avg_launch_ms)
+(cd /tmp && VD_OVERLAP=0 rocprofv3 --kernel-trace --output-format csv -d $O/prof_train_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_train_serial.json 2> $O/prof_train_serial.err)
+python tools/last_step_kernels.py $O/prof_train_serial $O/train_last_step_kernels_serial.json
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
