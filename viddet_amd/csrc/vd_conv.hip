@@ -1231,7 +1231,14 @@ int wgrad_bm(const vd_wgrad_desc& d) {
     return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
 }
 // workgroups resident at once: 2 per CU for the fp32-MFMA tiles, 1 per CU for the split-math tiles (LDS)
-int wgrad_slots(const vd_wgrad_desc& d) { return (wgrad_split_math(d) && d.Co >= 128) ? 256 : 512; }
+// A weight-gradient workgroup lives for its whole pixel range (0.2-1.3 ms) and, with 8 waves x 256 VGPRs, shares its CU
+// with nothing: a grid that fills all 256 CUs starves the critical-path stream it runs beside - the rocprofv3 timeline
+// showed a 44-block partial-sum reduction crawling through ONE free CU for 0.62 ms.  The grid is therefore sized for
+// 240 CUs (VD_WGRAD_RESERVE, default 16 withheld): +1.0 % on the training step, same-box A/B (688.7 vs 682.0 frames/s).
+int wgrad_slots(const vd_wgrad_desc& d) {
+    static const int reserve = getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 16;
+    return (wgrad_split_math(d) && d.Co >= 128) ? 256 - reserve : 512 - 2 * reserve;
+}
 
 int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
