@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${VD_PROFILE_TAG:-r01i}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${VD_PROFILE_TAG:-r01j}; mkdir -p $O
 cd $R
 python bench.py > $O/train_bench.json 2> $O/train_bench.err
 echo "train done"; cut -c1-160 $O/train_bench.json
