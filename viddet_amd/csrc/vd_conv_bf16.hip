@@ -23,7 +23,7 @@ constexpr int KCH = 64;                 // bf16 channels per K-step
 
 __device__ __attribute__((aligned(64))) float g_zero_page_b[64];
 
-// developer build (-DVD_STAMP=1, tools/stamp_bf16.py): wave 0 of one mid-grid workgroup records s_memtime at the
+// developer build (-DVD_STAMP=1, tools/stamp_conv.py): wave 0 of one mid-grid workgroup records s_memtime at the
 // phase boundaries of the kernel
 #ifndef VD_STAMP
 #define VD_STAMP 0
