@@ -110,9 +110,11 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream);
 int vd_conv_igemm_mtiles(const vd_conv_desc* d);
 
 /* bf16 variant of vd_conv_igemm for inference (BASELINE configs[1] asks for bf16; the reference is fp32-only):
- * in / wp / residual are bf16 (NHWC with Ci % 64 == 0, weights [Co][T*Ci]), accumulation and epilogue fp32,
+ * in / wp / residual are bf16 (NHWC with Ci % 64 == 0, or Ci == 32 unpadded: a K-step then holds two taps;
+ * weights [Co][T*Ci]), accumulation and epilogue fp32,
  * out is bf16 (out_f32 = 0) or fp32 (out_f32 = 1: prediction heads, shared decode / NMS kernels).
- * Forward geometry only (out_stride 1).  d->tile: 0 = default, 1..5 = tile variant. */
+ * Forward geometry only (out_stride 1).  d->tile: 0 = default, 1..13 = tile variant (256x256 .. 128x64; the
+ * host autotunes it). */
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
 /* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T,
