@@ -6,7 +6,8 @@ id >= 0, normalise boxes by W, collect [id, score, x1, y1, x2, y2] per image pat
 (one `path,id,score,x1,y1,x2,y2` text file per image), load_predictions/evaluate :333-448,659-695 (VOC mAP; the
 reference's `sid=` keyword bug at :693 is not reproduced), main :792-939 (net build :871-892).
 The network underneath is viddet_amd.model.YOLOV3 (hand-written HIP kernels).  Frames shard across ranks with
-no collective (inference = replicas only).  Visualisation / worst-video / COCO+VID metrics are out of scope.
+no collective on the data path (inference = replicas only); the per-image box lists are gathered to rank 0, which writes
+the prediction files and evaluates.  Visualisation / worst-video / COCO+VID metrics are out of scope.
 """
 import argparse
 import os
@@ -167,14 +168,26 @@ def main(argv=None):
         net.load_parameters(FLAGS.model_path)
     save_dir = os.path.join(FLAGS.save_dir, FLAGS.save_prefix, "pred")
     boxes = detect(net, dataset, loader, FLAGS.max_do)
+    if world > 1:
+        # frames are sharded over the ranks (replicas, no collective on the data path); the per-image box lists (host
+        # objects) are merged so that ONE rank writes every file - a rank must never write an (empty) file for an image
+        # another rank detected on - and evaluates the whole set as the reference's single process does
+        merged = dict()
+        for part in vdist.all_gather_objects(boxes):
+            merged.update(part)
+        boxes = merged
+        if rank != 0:
+            return None
     save_predictions(save_dir, dataset, boxes, max_do=FLAGS.max_do)
-    if "voc" in FLAGS.metrics and world == 1:
+    if "voc" in FLAGS.metrics:
         preds = load_predictions(save_dir, dataset, FLAGS.max_do)
         if hasattr(dataset, "parents") and hasattr(dataset, "wn_classes"):     # detect_yolo3.py:898-899 (class-tree sets)
             preds = hierarchical_nms(preds, dataset, level_thresh=FLAGS.hier_level)
         (names, values), = evaluate([VOCMApMetric(iou_thresh=0.5, class_names=dataset.classes)], dataset, preds,
                                     FLAGS.data_shape)
         print("{}={:.4f}".format(names[-1], values[-1]))
+        return names, values
+    return None
 
 
 if __name__ == "__main__":

@@ -234,7 +234,8 @@ int vd_fill(float* out, float v, int64_t n, void* stream);
  * out[n, y, x, 0:Cu) = up[n, y/2, x/2, :], out[..., Cu:Cu+Cr) = route[n, y, x, :] */
 int vd_upsample2x_concat(const float* up, const float* route, float* out,
                          int N, int Ho, int Wo, int Cu, int Cr, void* stream);
-/* backward: dup[n,y2,x2,:] = sum of the 4 children of dout[..., 0:Cu); droute = dout[..., Cu:) */
+/* backward: dup[n,y2,x2,:] = sum of the 4 children of dout[..., 0:Cu); droute = dout[..., Cu:).  Either output may be
+ * NULL (that gradient is not needed: every parameter upstream of it has grad_req 'null', wrappers.py:55-57). */
 int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute,
                              int N, int Ho, int Wo, int Cu, int Cr, void* stream);
 /* NCHW fp32 -> NHWC fp32 (the reference feeds NCHW, transforms.py:239-245) */

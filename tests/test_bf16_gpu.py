@@ -2,7 +2,8 @@
 The reference has no reduced precision, so the bound is defined here against the fp32 oracle:
   * a single conv on bf16-representable inputs is exact to fp32 accumulation error (products of bf16 are exact in fp32);
   * whole-network raw head outputs stay within 3 % of the head's max magnitude (bf16 has 8 significant bits and the
-    75-layer stack re-rounds every activation), and the detections keep their class and overlap the oracle's boxes."""
+    75-layer stack re-rounds every activation), and the detections keep their class and overlap the oracle's boxes
+    (IoU > 0.9; > 0.75 on the full 608x608 frame of BASELINE configs[1], whose larger logits carry larger absolute error)."""
 import ctypes as C
 
 import numpy as np
@@ -66,10 +67,11 @@ def test_conv_bf16_single_layer(tile, shape):
         assert maxdiff(got, ref) < tol
 
 
-def test_bf16_network_inference_close_to_fp32_oracle():
+@pytest.mark.parametrize("c,b,size,obj_bias", [(4, 2, 96, -1.0),
+                                               (20, 1, 608, -3.0)])     # BASELINE configs[1]: one full 608x608 frame
+def test_bf16_network_inference_close_to_fp32_oracle(c, b, size, obj_bias):
     from viddet_amd.model import yolo3_darknet53
-    c, b, size = 4, 2, 96
-    P = ON.init_params(c, seed=51, obj_bias=-1.0)
+    P = ON.init_params(c, seed=51, obj_bias=obj_bias)
     net = yolo3_darknet53(["c%d" % i for i in range(c)])
     for k, p in net.collect_params().items():
         p.set_data(torch.from_numpy(P[k].astype(np.float32)))
@@ -102,7 +104,9 @@ def test_bf16_network_inference_close_to_fp32_oracle():
                 iw = max(0.0, min(a[2], bq[2]) - max(a[0], bq[0])); ih = max(0.0, min(a[3], bq[3]) - max(a[1], bq[1]))
                 u = (a[2] - a[0]) * (a[3] - a[1]) + (bq[2] - bq[0]) * (bq[3] - bq[1]) - iw * ih
                 best = max(best, iw * ih / u if u > 0 else 0.0)
-            assert best > 0.9, (bi, j, best)
+            # full-size frame: raw wh logits carry up to ~0.12 of absolute error (1.2 % of max|head|, inside the 3 % bound
+            # above), i.e. e^0.12 on a box side: IoU down to ~0.8 (measured 0.815)
+            assert best > (0.9 if size < 608 else 0.75), (bi, j, best)
     net.set_precision('fp32')
     again = net(dev(x))
     torch.cuda.synchronize()

@@ -97,3 +97,69 @@ def test_shard_range_covers_without_overlap():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+def _val_records(idx, c=3):
+    """Deterministic fake detections / ground truth of validation sample `idx`."""
+    rng = np.random.default_rng(1000 + idx)
+    n, m = 5, 3
+    lo = rng.uniform(0, 60, (n, 2)); pb = np.concatenate([lo, lo + rng.uniform(5, 40, (n, 2))], axis=1)
+    gl = rng.integers(0, c, (m, 1)).astype(np.float64)
+    gb = pb[:m] + rng.uniform(-3, 3, (m, 4))            # the first m detections overlap a ground-truth box
+    pl = np.concatenate([gl[:, 0], rng.integers(0, c, n - m)]).reshape(n, 1).astype(np.float64)
+    ps = rng.uniform(0.05, 0.95, (n, 1))
+    return (idx, pb, pl, ps, gb, gl, None)
+
+
+def _metric_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from viddet_amd import dist as vd
+    from viddet_amd.metrics import VOCMApMetric, update_metric_sharded
+    vd.init_from_env(backend="gloo")
+    try:
+        nsamp = 9                                         # not divisible by the world size
+        names = ["a", "b", "c"]
+        m = VOCMApMetric(iou_thresh=0.5, class_names=names)
+        mine = [_val_records(i) for i in range(rank, nsamp, world)]     # Loader's frame sharding: idx[rank::world]
+        n = update_metric_sharded(m, mine)
+        full = VOCMApMetric(iou_thresh=0.5, class_names=names)
+        for i in range(nsamp):
+            _, pb, pl, ps, gb, gl, gd = _val_records(i)
+            full.update([pb], [pl], [ps], [gb], [gl], None)
+        assert n == nsamp
+        a, b = m.get()[1], full.get()[1]
+        assert np.allclose(a, b, rtol=0, atol=0, equal_nan=True), (a, b)      # the single-process metric, bit for bit
+        # a decision of rank 0 reaches every rank (train_yolov3.py start-up: refuse an existing save_dir together)
+        assert vd.broadcast_object(rank == 0 and "refuse", src=0) == "refuse"
+        vd.barrier()
+        q.put((rank, "ok", float(a[-1])))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "fail: %r" % (e,), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validation_metric_covers_the_whole_set_on_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metric_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0
+
+
+def test_loader_shards_cover_the_validation_set():
+    from viddet_amd.data import SyntheticDetection, YOLO3VideoInferenceTransform, Loader
+    ds = SyntheticDetection("voc", num_samples=7, size=(64, 48))
+    seen = []
+    for r in range(2):
+        ld = Loader(ds, YOLO3VideoInferenceTransform(32, 32), 2, train=False, last_batch="keep", rank=r, world=2)
+        for batch in ld:
+            seen += [int(i) for i in batch[-1]]
+    assert sorted(seen) == list(range(7))

@@ -33,8 +33,8 @@ def test_param_roundtrip_and_count():
 
 
 @pytest.mark.parametrize("cfg", [dict(b=2, c=4, size=64, seed=3), dict(b=1, c=20, size=96, seed=4),
-                                 dict(b=1, c=20, size=608, seed=5, obj_bias=-4.0)])     # one full 608x608 frame (objectness
-                                                                                      # prior low enough for the candidate cap)
+                                 dict(b=1, c=20, size=608, seed=5, obj_bias=1.0)])      # one full 608x608 frame, most of its
+                                                                                      # C*P = 454,860 rows above valid_thresh
 def test_inference_matches_oracle(cfg):
     b, c, size = cfg["b"], cfg["c"], cfg["size"]
     net, P = _mk_net(c, cfg["seed"], obj_bias=cfg.get("obj_bias", -1.0))
@@ -51,6 +51,8 @@ def test_inference_matches_oracle(cfg):
         ref = np.moveaxis(heads_r[s], 1, -1)
         assert maxdiff(got, ref) < 1e-3, "head %d" % s
     assert int(net.last_overflow.max()) == 0
+    if size == 608:      # more candidates than the 2^18 cap of round 1, which dropped rows in arrival order here
+        assert int(net._programs[('infer', b, size, size)][2]['counts'].max()) > (1 << 18)
     from tests.util import assert_rows_match, take_ranks
     perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
     ids, sc, bx = [torch.from_numpy(take_ranks(t, perm)) for t in (ids, sc, bx)]
@@ -131,6 +133,88 @@ def test_training_step_matches_oracle(cfg):
         gdev = net.collect_params()[k].grad().cpu().numpy().astype(np.float64)
         wr, _ = R.sgd_momentum(w0[k], gdev, np.zeros_like(gdev), 0.01, 0.9, 5e-4, 1.0 / b)
         assert maxdiff(net.collect_params()[k].data().cpu().numpy(), wr) < 1e-6, k
+
+
+def test_freeze_base_leaves_the_backbone_untouched():
+    """wrappers.py:55-57: freeze_base sets grad_req = 'null' on every Darknet parameter - no gradient, no update, no
+    weight decay for stages.*; the neck / heads train exactly as in the unfrozen network (their gradients do not
+    depend on anything below the three route tensors); BatchNorm still normalises with batch statistics and moves
+    its running statistics (training mode).  The backward schedule drops the backbone's launches altogether."""
+    from viddet_amd.model import yolo3_darknet53
+    b, c, size, m = 2, 4, 64, 3
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+    gt, tg = _targets(rng, b, c, size, m)
+    P = ON.init_params(c, seed=8, obj_bias=-1.0)
+    nets = []
+    for freeze in (False, True):
+        net = yolo3_darknet53(["c%d" % i for i in range(c)], freeze_base=freeze)
+        for k, p in net.collect_params().items():
+            p.set_data(torch.from_numpy(P[k].astype(np.float32)))
+        nets.append(net)
+    free, frozen = nets
+    assert all(p.grad_req == 'null' for k, p in frozen.collect_params('stages.*').items())
+    assert all(p.grad_req == 'write' for k, p in frozen.collect_params('(yolo|trans).*(weight|gamma|beta|bias)').items())
+    outs = []
+    before = {k: p.data().clone() for k, p in frozen.collect_params().items()}
+    for net in nets:
+        out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+        net.backward()
+        outs.append([o.clone() for o in out])
+    torch.cuda.synchronize()
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)                  # the forward pass is the same program
+    nw = lambda net: sum(1 for seg in net._last_train['bwd'] if hasattr(seg, 'recs') for r in seg.recs
+                         if r[0] in ('vd_conv_wgrad', 'vd_stem_wgrad'))
+    assert nw(free) == 75 and nw(frozen) == 75 - 52, (nw(free), nw(frozen))
+    for net in nets:
+        net.sgd_step(lr=0.01, momentum=0.9, wd=5e-4, batch_size=b)
+    torch.cuda.synchronize()
+    for k, p in frozen.collect_params().items():
+        now = p.data()
+        if k.startswith("stages") and "running" not in k:
+            assert torch.equal(now, before[k]), "frozen tensor %s changed" % k
+            assert float(p.grad().abs().max()) == 0.0, k
+        elif k.startswith("stages"):
+            assert not torch.equal(now, before[k]), "running statistic %s did not move" % k
+        else:
+            # same gradient as in the unfrozen network (same launches on the same inputs; tile choices of the two plans
+            # may differ, hence a tolerance) and the same update
+            if "running" not in k:
+                g0, g1 = free.collect_params()[k].grad(), p.grad()
+                assert float((g0 - g1).abs().max()) <= 1e-5 * max(1e-3, float(g0.abs().max())), k
+                assert float((free.collect_params()[k].data() - now).abs().max()) <= 1e-7 + 1e-5 * float(now.abs().max()), k
+                assert not torch.equal(now, before[k]), k
+    assert float(frozen.momentum_buf[:frozen.conv_nodes[52].w_off].abs().max()) == 0.0
+    # thawing rebuilds the schedule
+    for k, p in frozen.collect_params('stages.*(weight|gamma|beta)').items():
+        p.grad_req = 'write'
+    frozen(dev(x), dev(gt), *[dev(t) for t in tg])
+    frozen.backward()
+    torch.cuda.synchronize()
+    assert nw(frozen) == 75
+
+
+def test_wd_mult_and_lr_mult_are_applied():
+    """Per-parameter multipliers of the optimiser (train_yolov3.py:495-497 sets wd_mult = 0 on gamma / beta / bias)."""
+    net, P = _mk_net(4, 9, obj_bias=-1.0)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    gt, tg = _targets(rng, 2, 4, 64, 3)
+    net(dev(x), dev(gt), *[dev(t) for t in tg])
+    net.backward()
+    pg, pw = net.collect_params()["yolo_blocks.1.body.2.1.gamma"], net.collect_params()["yolo_blocks.0.tip.0.weight"]
+    pg.wd_mult = 0.0
+    pw.lr_mult, pw.wd_mult = 0.5, 2.0
+    others = ["transitions.0.1.beta", "stages.1.3.body.1.0.weight"]
+    w0 = {k: net.collect_params()[k].data().cpu().numpy().astype(np.float64) for k in [pg.name, pw.name] + others}
+    g = {k: net.collect_params()[k].grad().cpu().numpy().astype(np.float64) for k in w0}
+    net.sgd_step(lr=0.01, momentum=0.9, wd=5e-4, batch_size=2)
+    torch.cuda.synchronize()
+    for k, (lm, wm) in {pg.name: (1.0, 0.0), pw.name: (0.5, 2.0), others[0]: (1.0, 1.0), others[1]: (1.0, 1.0)}.items():
+        wr, _ = R.sgd_momentum(w0[k], g[k], np.zeros_like(g[k]), 0.01 * lm, 0.9, 5e-4 * wm, 0.5)
+        assert maxdiff(net.collect_params()[k].data().cpu().numpy(), wr) < 1e-6, k
+    assert len(net._optimizer_ranges()) >= 4
 
 
 def test_reset_class_reuses_rows():

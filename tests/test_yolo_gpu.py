@@ -41,6 +41,8 @@ def _oracle_detect(heads, c, topk=400, post=100):
     dict(b=1, c=80, grids=[7, 14, 28], obj_bias=-2.0, seed=23),          # C > 64: two class sweeps per anchor
     dict(b=3, c=4, grids=[2, 4, 8], obj_bias=-9.0, seed=24),             # (almost) nothing passes
     dict(b=1, c=20, grids=[5, 10, 20], obj_bias=3.0, cls_bias=2.0, seed=25),   # everything passes, heavy overlap
+    dict(b=2, c=285, grids=[4, 8, 16], obj_bias=-2.0, seed=28),          # combined set (configs[4]): A = 870, 5 class sweeps
+    dict(b=1, c=285, grids=[19, 38, 76], obj_bias=-3.0, seed=29),        # ... at the full 608x608 grids (C*P = 6.48 M rows)
 ])
 def test_decode_filter_nms(cfg):
     from viddet_amd import ops
@@ -83,6 +85,45 @@ def test_decode_filter_nms(cfg):
     assert maxdiff(bx.cpu().numpy(), bx_r) < 1e-3
 
 
+def test_nms_all_pass_with_exact_score_ties_keeps_row_order():
+    """Every one of the C*P rows passes valid_thresh and the scores take only ~40 distinct values, so thousands of rows
+    tie exactly at the top-400 threshold: the kept set must be the oracle's (stable sort = lowest original rows first,
+    SURVEY A.2), whatever order the filter's atomics appended the candidates in.  Objectness logits of +20 make
+    sigmoid(obj) == 1.0f on the device and 1 - 2e-9 in the fp64 oracle - a common factor - and class logits on a 0.1
+    grid keep distinct scores >= 1e-3 apart, so both sides rank identically and tie exactly where the logits are equal."""
+    from viddet_amd import ops
+    b, c, grids = 2, 20, [5, 10, 20]
+    rng = np.random.default_rng(27)
+    heads = _heads(rng, b, c, grids, 0.0)
+    for hh in heads:
+        v = hh.reshape(b, 3, 5 + c, hh.shape[2], hh.shape[3])
+        v[:, :, 4] = 20.0
+        v[:, :, 5:] = np.round(rng.uniform(-2.0, 2.0, v[:, :, 5:].shape) * 10.0) / 10.0
+    (ids_r, sc_r, bx_r, rows_r), alldet = _oracle_detect(heads, c)
+    assert (alldet[..., 1] > 0.01).all()
+    kth = np.sort(alldet[0, :, 1])[-400]
+    assert (alldet[0, :, 1] == kth).sum() > 50, "fixture has no mass tie at the top-k threshold"
+    h, hd, _, _ = _desc(ops, heads, c, b)
+    cap = c * 3 * sum(g * g for g in grids)
+    cs = torch.empty(b, cap, device="cuda"); cr = torch.empty(b, cap, dtype=torch.int32, device="cuda")
+    cnt = torch.empty(b, dtype=torch.int32, device="cuda")
+    ids = torch.empty(b, 100, device="cuda"); sc = torch.empty(b, 100, device="cuda")
+    bx = torch.empty(b, 100, 4, device="cuda"); rows = torch.empty(b, 100, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    first = None
+    for rep in range(3):                    # the append order differs from launch to launch; the result must not
+        ops.yolo_decode_filter(h, 0.01, cs, cr, cap, cnt)
+        ops.nms_topk(h, cs, cr, cap, cnt, 0.45, 400, 100, ids, sc, bx, rows, ws)
+        torch.cuda.synchronize()
+        assert int(cnt.min()) == cap and int(ws.view(torch.int32)[:b].max()) == 0
+        got = rows.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, rows_r), "post-NMS row indices differ under exact score ties"
+        first = got if first is None else first
+        assert np.array_equal(got, first)
+    assert np.array_equal(ids.cpu().numpy(), ids_r[..., 0])
+    assert maxdiff(bx.cpu().numpy(), bx_r) < 1e-3
+
+
 def test_decode_filter_cap_overflow_reported():
     from viddet_amd import ops
     b, c, grids = 1, 20, [5, 10, 20]
@@ -119,6 +160,8 @@ def _gt(rng, b, m, size, c, nvalid):
     dict(b=3, c=80, size=160, m=6, nvalid=[6, 0, 2], smooth=False, seed=32),     # an image with no gt
     dict(b=2, c=20, size=128, m=5, nvalid=[5, 4], smooth=True, seed=33),         # label smoothing
     dict(b=1, c=30, size=416, m=8, nvalid=[8], smooth=False, seed=34),           # full 416 grid
+    dict(b=2, c=285, size=96, m=5, nvalid=[4, 2], smooth=False, seed=35),        # combined set: 285 classes
+    dict(b=1, c=285, size=608, m=8, nvalid=[8], smooth=True, seed=36),           # ... one full 608x608 frame, smoothed
 ])
 def test_loss_fwd_bwd(cfg):
     from viddet_amd import ops

@@ -44,14 +44,18 @@ def device_leaky_masks(net, bufs):
     return out
 
 
-def check_masks_differ_only_at_ties(onet_natural_pre, masks, band=2e-4):
-    """The supplied decisions may differ from the oracle's own only where the oracle's |pre-activation| is tiny."""
-    nflip = 0
+def check_masks_differ_only_at_ties(onet_natural_pre, masks, band=5e-5):
+    """The supplied decisions may differ from the oracle's own only where the oracle's |pre-activation| is tiny
+    (below `band`: fp32 round-off of the device's conv stack around an exact zero crossing; the largest seen on the
+    full-size 416x416 frame is 1.2e-5, deep in the neck, where 70 layers of fp32 round-off have accumulated)."""
+    nflip, worst = 0, 0.0
     for name, u in onet_natural_pre.items():
         diff = (u > 0) != masks[name]
         if diff.any():
+            worst = max(worst, float(np.abs(u[diff]).max()))
             assert np.abs(u[diff]).max() < band, (name, float(np.abs(u[diff]).max()))
             nflip += int(diff.sum())
+    print("leaky branch ties: %d flips, largest |pre-activation| among them %.2e (band %.0e)" % (nflip, worst, band))
     return nflip
 
 

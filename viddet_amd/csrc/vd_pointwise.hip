@@ -221,16 +221,21 @@ int vd_upsample2x_concat(const float* up, const float* route, float* out, int N,
 
 int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute, int N, int Ho, int Wo, int Cu, int Cr,
                              void* stream) {
-    VD_REQUIRE(dout && dup && droute && N > 0 && Ho % 2 == 0 && Wo % 2 == 0 && Cu % 4 == 0 && Cr % 4 == 0,
+    // dup / droute may be NULL: that half is not needed (no trainable parameter upstream of it, grad_req 'null')
+    VD_REQUIRE(dout && (dup || droute) && N > 0 && Ho % 2 == 0 && Wo % 2 == 0 && Cu % 4 == 0 && Cr % 4 == 0,
                "vd_upsample2x_concat_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t t1 = (int64_t)N * (Ho / 2) * (Wo / 2) * (Cu / 4);
-    hipLaunchKernelGGL(k_upcat_bwd_up, dim3(sblocks(t1)), dim3(256), 0, s, dout, dup, N, Ho, Wo, Cu / 4, (Cu + Cr) / 4);
-    VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/up");
-    const int64_t npix = (int64_t)N * Ho * Wo;
-    hipLaunchKernelGGL(k_upcat_bwd_route, dim3(sblocks(npix * (Cr / 4))), dim3(256), 0, s, dout, droute, npix, Cu / 4,
-                       Cr / 4);
-    VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/route");
+    if (dup) {
+        const int64_t t1 = (int64_t)N * (Ho / 2) * (Wo / 2) * (Cu / 4);
+        hipLaunchKernelGGL(k_upcat_bwd_up, dim3(sblocks(t1)), dim3(256), 0, s, dout, dup, N, Ho, Wo, Cu / 4, (Cu + Cr) / 4);
+        VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/up");
+    }
+    if (droute) {
+        const int64_t npix = (int64_t)N * Ho * Wo;
+        hipLaunchKernelGGL(k_upcat_bwd_route, dim3(sblocks(npix * (Cr / 4))), dim3(256), 0, s, dout, droute, npix, Cu / 4,
+                           Cr / 4);
+        VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/route");
+    }
     return VD_OK;
 }
 

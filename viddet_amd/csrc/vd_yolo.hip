@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
     __shared__ int bcls[TOPK_MAX];
     __shared__ unsigned long long smask[TOPK_MAX * (TOPK_MAX / 64)];
     __shared__ unsigned int hist[256];
-    __shared__ unsigned int s_prefix, s_kth, s_cnt;
+    __shared__ unsigned int s_prefix_hi, s_prefix_lo, s_kth, s_cnt;
     __shared__ int keep[TOPK_MAX];
     __shared__ int s_nkeep;
 
@@ -175,16 +175,27 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
     if (n <= SORT_N) {
         if (tid < n) skey[tid] = ((unsigned long long)(~__float_as_uint(cs[tid])) << 32) | (unsigned int)cr[tid];
     } else {
-        // radix select of the topk-th largest score key (scores > 0 => uint order == float order)
-        if (tid == 0) { s_prefix = 0; s_kth = (unsigned)topk; }
-        for (int pass = 3; pass >= 0; --pass) {
+        // Exact top-k of the candidate list, independent of the order the filter's atomics appended it in: radix
+        // select (8 digits of 8 bits, most significant first) of the topk-th largest 64-bit key
+        //     key = score bits << 32 | (0xFFFFFFFF - row)      (scores > 0 => uint order == float order)
+        // i.e. score descending, then ORIGINAL ROW ascending - the order a stable sort of the reference's
+        // (B, C*P, 6) tensor gives.  Rows are unique, so keys are unique and exactly `topk` keys are
+        // >= the selected one: rows tied at the threshold score are kept by row order, never by arrival order.
+        if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_kth = (unsigned)topk; }
+        for (int pass = 7; pass >= 0; --pass) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            const unsigned prefix = s_prefix;
-            const int hs = 8 * (pass + 1);
+            const unsigned phi = s_prefix_hi, plo = s_prefix_lo;
             for (int i = tid; i < n; i += NMS_THREADS) {
                 const unsigned k = __float_as_uint(cs[i]);
-                if (pass == 3 || (k >> hs) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1u);
+                if (pass >= 4) {                       // score digits: prefix = the digits above this one
+                    const int hs = 8 * (pass - 3);
+                    if (pass == 7 || (k >> hs) == phi) atomicAdd(&hist[(k >> (8 * (pass - 4))) & 255u], 1u);
+                } else if (k == phi) {                 // row digits, only among rows tied at the threshold score
+                    const unsigned r = 0xFFFFFFFFu - (unsigned)cr[i];
+                    const int hs = 8 * (pass + 1);
+                    if (pass == 3 || (r >> hs) == plo) atomicAdd(&hist[(r >> (8 * pass)) & 255u], 1u);
+                }
             }
             __syncthreads();
             if (tid == 0) {
@@ -194,16 +205,18 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
                     if (cum + hist[d] >= kth) break;
                     cum += hist[d];
                 }
-                s_prefix = (prefix << 8) | (unsigned)d;
+                if (pass >= 4) s_prefix_hi = (phi << 8) | (unsigned)d;
+                else s_prefix_lo = (plo << 8) | (unsigned)d;
                 s_kth = kth - cum;
             }
             __syncthreads();
         }
-        const unsigned T = s_prefix;
+        const unsigned Ts = s_prefix_hi, Tr = s_prefix_lo;
         for (int i = tid; i < n; i += NMS_THREADS) {
             const unsigned k = __float_as_uint(cs[i]);
-            if (k >= T) {
-                const unsigned slot = atomicAdd(&s_cnt, 1u);
+            const unsigned r = 0xFFFFFFFFu - (unsigned)cr[i];
+            if (k > Ts || (k == Ts && r >= Tr)) {
+                const unsigned slot = atomicAdd(&s_cnt, 1u);       // exactly topk <= SORT_N of them; the sort orders them
                 if (slot < SORT_N) skey[slot] = ((unsigned long long)(~k) << 32) | (unsigned int)cr[i];
             }
         }

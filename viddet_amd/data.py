@@ -200,8 +200,10 @@ class Loader:
         self.rank, self.world = rank, world
 
     def __len__(self):
-        n = len(self.ds) // self.world
-        return n // self.bs if self.last_batch != "keep" else (n + self.bs - 1) // self.bs
+        if self.last_batch == "keep":                    # every sample of this rank's shard (validation / detection)
+            n = len(range(self.rank, len(self.ds), self.world))
+            return (n + self.bs - 1) // self.bs
+        return (len(self.ds) // self.world) // self.bs   # training: the same number of batches on every rank
 
     def __iter__(self):
         idx = np.arange(len(self.ds))

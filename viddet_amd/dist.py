@@ -69,3 +69,26 @@ def bucketed_allreduce_sum_(flat, bucket_elems, group=None, async_op=False):
         if async_op:
             handles.append(h)
     return handles
+
+
+def all_gather_objects(obj, group=None):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (host objects: detections, metric records); [obj] for one rank."""
+    if not active(group):
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def broadcast_object(obj, src=0, group=None):
+    """Rank `src`'s host object on every rank (a decision every rank must take identically)."""
+    if not active(group):
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def barrier(group=None):
+    if active(group):
+        dist.barrier(group=group)

@@ -151,3 +151,17 @@ class VOCMApMetricTemporal:
             names += ["%s t=%d/%d" % (x, t, self.t) for x in nm]                # :326
             values += list(vals)
         return names, values
+
+
+def update_metric_sharded(metric, records, group=None):
+    """Validation under frame-batch data parallelism: every rank evaluated its shard of the validation set; the
+    reference evaluates the WHOLE set in one process (train_yolov3.py:434-489).  `records` = this rank's
+    [(sample index, det_bboxes, det_ids, det_scores, gt_bboxes, gt_ids, gt_difficults or None)], one per image.  All
+    ranks exchange their records (host objects, a few KB per image) and update `metric` with every image in sample
+    order, so each rank holds the single-process metric - the mAP that picks *_best.params is the full-set mAP."""
+    from . import dist as vdist
+    merged = [r for part in vdist.all_gather_objects(list(records), group) for r in part]
+    merged.sort(key=lambda r: int(r[0]))
+    for _, pb, pl, ps, gb, gl, gd in merged:
+        metric.update([pb], [pl], [ps], [gb], [gl], None if gd is None else [gd])
+    return len(merged)

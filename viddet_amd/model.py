@@ -237,14 +237,50 @@ def autotune_program(prog, reps=3):
 
 
 class Parameter:
-    """Gluon-Parameter-like handle (name, shape in the reference's layout, wd_mult, grad_req)."""
+    """Gluon-Parameter-like handle (name, shape in the reference's layout, wd_mult, lr_mult, grad_req).  The three
+    attributes are live, as in Gluon: `grad_req = 'null'` (wrappers.py:55-57 freeze_base) removes the parameter from the
+    backward schedule and from the optimiser (no gradient, no update, no weight decay); `wd_mult` / `lr_mult` scale
+    the optimiser's wd / lr for this parameter (train_yolov3.py:495-497 sets wd_mult = 0 with --no_wd)."""
 
     def __init__(self, net, name, shape, kind, node=None, trainable=True):
         self._net, self.name, self.shape, self.kind, self.node = net, name, tuple(shape), kind, node
-        self.wd_mult, self.lr_mult = 1.0, 1.0
-        self.grad_req = 'write' if trainable else 'null'
+        self._wd_mult, self._lr_mult = 1.0, 1.0
+        self._grad_req = 'write' if trainable else 'null'
         self.storage = None      # view into an arena (device layout)
         self.grad_storage = None
+        self.span = None         # [lo, hi) of the parameter arena (None: not in the arena, e.g. running statistics)
+
+    @property
+    def wd_mult(self):
+        return self._wd_mult
+
+    @wd_mult.setter
+    def wd_mult(self, v):
+        self._wd_mult = float(v)
+        self._net._opt_ranges = None
+
+    @property
+    def lr_mult(self):
+        return self._lr_mult
+
+    @lr_mult.setter
+    def lr_mult(self, v):
+        self._lr_mult = float(v)
+        self._net._opt_ranges = None
+
+    @property
+    def grad_req(self):
+        return self._grad_req
+
+    @grad_req.setter
+    def grad_req(self, v):
+        if v not in ('write', 'null'):
+            raise NotImplementedError("grad_req %r: only 'write' and 'null' are built (the reference uses no 'add')" % (v,))
+        if self.span is None and v != 'null':
+            raise ValueError("%s is an auxiliary state (no gradient)" % self.name)
+        if v != self._grad_req:
+            self._grad_req = v
+            self._net._grad_req_changed()
 
     # reference layout <-> device layout (conv weights are kept fwd-packed [Co_pad][T*Ci])
     def data(self):
@@ -573,9 +609,11 @@ class YOLOV3(object):
     def _make_params(self):
         P = ParameterDict()
 
-        def reg(name, shape, kind, node, storage, gstorage, trainable=True):
+        def reg(name, shape, kind, node, storage, gstorage, trainable=True, off=None):
             p = Parameter(self, name, shape, kind, node, trainable)
             p.storage, p.grad_storage = storage, gstorage
+            if off is not None:
+                p.span = (off, off + round_up(storage.numel(), 64))
             P[name] = p
             return p
 
@@ -584,13 +622,13 @@ class YOLOV3(object):
             gv = self.grads[n.w_off:n.w_off + n.w_numel]
             n.wp, n.gwp = wv, gv
             if n.head:
-                reg(n.name + ".weight", (n.cout, n.cin, 1, 1), 'conv_weight', n, wv, gv)
+                reg(n.name + ".weight", (n.cout, n.cin, 1, 1), 'conv_weight', n, wv, gv, off=n.w_off)
                 n.bias = self.weights[n.bias_off:n.bias_off + n.co_pad]
                 n.gbias = self.grads[n.bias_off:n.bias_off + n.co_pad]
-                reg(n.name + ".bias", (n.cout,), 'vector', n, n.bias, n.gbias)
+                reg(n.name + ".bias", (n.cout,), 'vector', n, n.bias, n.gbias, off=n.bias_off)
             else:
                 kind = 'stem_weight' if n.stem else 'conv_weight'
-                reg(n.name + ".0.weight", n.weight_shape(), kind, n, wv, gv)
+                reg(n.name + ".0.weight", n.weight_shape(), kind, n, wv, gv, off=n.w_off)
                 n.gamma = self.weights[n.gamma_off:n.gamma_off + n.cout]
                 n.beta = self.weights[n.beta_off:n.beta_off + n.cout]
                 n.ggamma = self.grads[n.gamma_off:n.gamma_off + n.cout]
@@ -598,11 +636,12 @@ class YOLOV3(object):
                 c64 = round_up(n.cout, 64)
                 n.rmean = self.running[n.stat_off:n.stat_off + n.cout]
                 n.rvar = self.running[n.stat_off + c64:n.stat_off + c64 + n.cout]
-                reg(n.name + ".1.gamma", (n.cout,), 'vector', n, n.gamma, n.ggamma)
-                reg(n.name + ".1.beta", (n.cout,), 'vector', n, n.beta, n.gbeta)
+                reg(n.name + ".1.gamma", (n.cout,), 'vector', n, n.gamma, n.ggamma, off=n.gamma_off)
+                reg(n.name + ".1.beta", (n.cout,), 'vector', n, n.beta, n.gbeta, off=n.beta_off)
                 reg(n.name + ".1.running_mean", (n.cout,), 'vector', n, n.rmean, None, trainable=False)
                 reg(n.name + ".1.running_var", (n.cout,), 'vector', n, n.rvar, None, trainable=False)
         self._params = P
+        self._opt_ranges = None
 
     # ------------------------------------------------------------------ reference-style surface
     @property
@@ -695,6 +734,36 @@ class YOLOV3(object):
                         new[5 + k + a * new_npred] = od[5 + v + a * old_npred]
                         new[a * new_npred:a * new_npred + 5] = od[a * old_npred:a * old_npred + 5]
             p.set_data(new)
+
+    def _grad_req_changed(self):
+        """A parameter was frozen / unfrozen: the backward schedule and the optimiser ranges are rebuilt on next use."""
+        self._programs = {k: v for k, v in self._programs.items() if k[0] != 'train'}
+        self._opt_ranges = None
+
+    def _node_trainable(self, n):
+        """(weight trainable, any of gamma / beta / bias trainable) of a conv node."""
+        P = self._params
+        if n.head:
+            return P[n.name + ".weight"].grad_req != 'null', P[n.name + ".bias"].grad_req != 'null'
+        return (P[n.name + ".0.weight"].grad_req != 'null',
+                P[n.name + ".1.gamma"].grad_req != 'null' or P[n.name + ".1.beta"].grad_req != 'null')
+
+    def _optimizer_ranges(self):
+        """Contiguous arena ranges [(lo, hi, lr_mult, wd_mult)] of the trainable parameters, adjacent parameters with
+        equal multipliers merged: two ranges (weights | gamma, beta, bias) for a fully trainable network."""
+        if self._opt_ranges is None:
+            ps = sorted((p for p in self._params.values() if p.span is not None and p.grad_req != 'null'),
+                        key=lambda p: p.span[0])
+            out = []
+            for p in ps:
+                lo, hi = p.span
+                if out and out[-1][1] == lo and out[-1][2] == p.lr_mult and out[-1][3] == p.wd_mult and \
+                        (lo != self.n_weight):
+                    out[-1][1] = hi
+                else:
+                    out.append([lo, hi, p.lr_mult, p.wd_mult])
+            self._opt_ranges = [tuple(r) for r in out]
+        return self._opt_ranges
 
     def _params_changed(self):
         self._fold_dirty = True
@@ -819,7 +888,10 @@ class YOLOV3(object):
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
                                 STRIDES[::-1], ANCHORS[::-1], Bh, self.num_class)
         P = 3 * sum(g * g for g in grids)
-        cap = min(self.num_class * P, 1 << 18)
+        # one candidate slot per row of the reference's (B, C*P, 6) tensor: box_nms (yolo3.py:1197-1202) has no cap, and an
+        # untrained net (validation after epoch 0) passes valid_thresh on every row.  8 bytes x C*P per image (14.6 MB at
+        # 608x608 / 80 classes) is address space, not traffic: only the rows that pass are ever written or read.
+        cap = self.num_class * P
         o = dict(cand_score=torch.empty(Bh, cap, device=self.device),
                  cand_row=torch.empty(Bh, cap, dtype=torch.int32, device=self.device),
                  counts=torch.zeros(Bh, dtype=torch.int32, device=self.device),
@@ -917,7 +989,7 @@ class YOLOV3(object):
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
                                 STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
         P = 3 * sum(g * g for g in grids)
-        cap = min(self.num_class * P, 1 << 18)
+        cap = self.num_class * P          # no candidate cap (see _build_infer)
         o = dict(cand_score=torch.empty(B, cap, device=dev), cand_row=torch.empty(B, cap, dtype=torch.int32, device=dev),
                  counts=torch.zeros(B, dtype=torch.int32, device=dev), ids=torch.empty(B, self.post_nms, 1, device=dev),
                  scores=torch.empty(B, self.post_nms, 1, device=dev), bboxes=torch.empty(B, self.post_nms, 4, device=dev),
@@ -1228,6 +1300,20 @@ class YOLOV3(object):
                 if t:
                     consumers.setdefault(t, []).append(m)
         fused_bwd = set()
+        # grad_req 'null' (wrappers.py:55-57): a tensor needs a gradient only if a trainable parameter sits in its
+        # producer or anywhere upstream of it.  With the backbone frozen nothing below the three route tensors does, so
+        # the whole backbone drops out of the backward schedule (as MXNet's autograd prunes it) and its weight-gradient
+        # launches never run.
+        tgrad = {t: False for t in self.tensors}
+        for m in self.nodes:
+            if isinstance(m, ConvNode):
+                tgrad[m.dst] = any(self._node_trainable(m)) or tgrad[m.src] or bool(m.residual and tgrad[m.residual])
+            elif isinstance(m, UpcatNode):
+                tgrad[m.dst] = tgrad[m.up] or tgrad[m.route]
+            else:
+                tgrad[m.dst] = tgrad[m.src]
+        wtrain = [m for m in self.conv_nodes if self._node_trainable(m)[0]]
+        first_wtrain = wtrain[0] if wtrain else None       # its weight gradient is the last one backward produces
 
         def materialize(name):
             if name in alias:
@@ -1247,20 +1333,30 @@ class YOLOV3(object):
 
         for n in reversed(self.nodes):
             if isinstance(n, UpcatNode):
+                if not tgrad[n.dst]:
+                    continue
                 dout = bufs['d:' + n.dst]
-                dup, acc_u = grad_into(n.up, 0)
-                drt, acc_r = grad_into(n.route, 0)
-                assert not acc_u
+                dup_p = drt_p = None                       # NULL = that half is not needed (frozen upstream)
+                acc_r = False
+                if tgrad[n.up]:
+                    dup, acc_u = grad_into(n.up, 0)
+                    assert not acc_u
+                    dup_p = dup.data_ptr()
+                if tgrad[n.route]:
+                    drt, acc_r = grad_into(n.route, 0)
+                    drt_p = drt.data_ptr()
                 if acc_r:
                     tmp = bufs['tmp'][:drt.numel()]
-                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), tmp.data_ptr(), B * n.fr,
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup_p, tmp.data_ptr(), B * n.fr,
                             dout.shape[1], dout.shape[2], n.cu, n.cr)
                     seg.add('vd_add', drt.data_ptr(), tmp.data_ptr(), drt.data_ptr(), drt.numel())
-                else:
-                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup.data_ptr(), drt.data_ptr(), B * n.fr,
+                elif dup_p or drt_p:
+                    seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup_p, drt_p, B * n.fr,
                             dout.shape[1], dout.shape[2], n.cu, n.cr)
                 continue
             if isinstance(n, PoolNode):
+                if not tgrad[n.src]:
+                    continue
                 dout = bufs['d:' + n.dst]
                 assert n.dst in written, n.name
                 dsrc, acc = grad_into(n.src, 0)
@@ -1277,6 +1373,9 @@ class YOLOV3(object):
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
             M = B * n.fr * Ho * Wo
+            if not tgrad[n.dst]:
+                continue                   # frozen, and nothing trainable upstream: no gradient is needed here
+            w_train, v_train = self._node_trainable(n)
             dy = bufs['d:' + n.dst]
             assert n.dst in written, n.name
             materialize(n.dst)
@@ -1286,7 +1385,7 @@ class YOLOV3(object):
                 seg.add('vd_bn_stats', dz.data_ptr(), M, n.co_pad, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
                 seg.add('vd_bn_param_grads', n.sums.data_ptr(), n.co_pad, bufs['tmp'].data_ptr(), n.gbias.data_ptr())
             else:
-                if n.residual:
+                if n.residual and tgrad[n.residual]:
                     dres, acc = grad_into(n.residual, 0)
                     if acc:
                         seg.add('vd_add', dres.data_ptr(), dy.data_ptr(), dres.data_ptr(), dy.numel())
@@ -1315,7 +1414,7 @@ class YOLOV3(object):
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
                         dz.data_ptr())
             # weight gradient straight into the gradient arena (same fwd-packed layout as the weights)
-            if n.stem:
+            if n.stem and w_train:
                 # both operands straight from global memory: the NCHW batch and dz (vd_stem.hip)
                 wargs = ('vd_stem_wgrad', bufs['in'].data_ptr(), dz.data_ptr(), n.co_pad, n.gwp.data_ptr(), B * n.fr, Hi, Wi)
                 if side is not None:
@@ -1334,40 +1433,43 @@ class YOLOV3(object):
                     seg.add_py(self._bucket_launcher(n.w_off, bucket_hi[0], side))
                     bucket_hi[0], bucket_acc[0] = n.w_off, 0
                 continue
-            wd_ = WgradDesc()
-            xin = bufs[n.src]
-            wd_.in_, wd_.dout, wd_.dwp = xin.data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
-            wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B * n.fr, Hi, Wi, n.ci_eff
-            wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, n.co_pad
-            wd_.in_stride = n.stride
-            ops._set_taps(wd_, n.taps())
-            wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
-            autotune_wgrad(wd_, ws.data_ptr(), ws_bytes)
-            seg.hold(wd_)
-            if side is not None:
-                e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
-                seg.add_py(ev_record(e_ready, False))
-                seg.add_py(ev_wait(e_ready, True))
-                seg.add('vd_conv_wgrad', C.byref(wd_), ws_w.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'),
-                        stream=side)
-                seg.add_py(ev_record(e_done, True))
-                seg.hold(e_ready, e_done)
-                if not n.head:
-                    dz_free[slot] = e_done
-                last_side[0] = e_done
-            else:
-                seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
-            # bucketed gradient all-reduce, overlapped with the rest of the backward pass: weight gradients complete
-            # in reverse arena order on the stream that runs the wgrad GEMMs, so every time a bucket (~32 MB) of the arena tail
-            # is final an async all-reduce of that contiguous range is queued behind them (RCCL syncs with that
-            # stream); allreduce_grads() later waits for the handles and reduces the small gamma/beta/bias range.
-            bucket_acc[0] += n.w_numel
-            if self.bucketed_allreduce and (bucket_acc[0] >= self.bucket_elems or n is self.conv_nodes[0]):
-                lo, hi = n.w_off, bucket_hi[0]
-                seg.add_py(self._bucket_launcher(lo, hi, side))
-                bucket_hi[0], bucket_acc[0] = lo, 0
-            if n.stem or n.src in self.input_tensors:     # no gradient flows into the network inputs
+            if n.stem:
                 continue
+            if w_train:
+                wd_ = WgradDesc()
+                xin = bufs[n.src]
+                wd_.in_, wd_.dout, wd_.dwp = xin.data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
+                wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B * n.fr, Hi, Wi, n.ci_eff
+                wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, n.co_pad
+                wd_.in_stride = n.stride
+                ops._set_taps(wd_, n.taps())
+                wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
+                autotune_wgrad(wd_, ws.data_ptr(), ws_bytes)
+                seg.hold(wd_)
+                if side is not None:
+                    e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
+                    seg.add_py(ev_record(e_ready, False))
+                    seg.add_py(ev_wait(e_ready, True))
+                    seg.add('vd_conv_wgrad', C.byref(wd_), ws_w.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'),
+                            stream=side)
+                    seg.add_py(ev_record(e_done, True))
+                    seg.hold(e_ready, e_done)
+                    if not n.head:
+                        dz_free[slot] = e_done
+                    last_side[0] = e_done
+                else:
+                    seg.add('vd_conv_wgrad', C.byref(wd_), ws.data_ptr(), ws_bytes, meta=self._flops(n, B, H, W, 'wgrad'))
+                # bucketed gradient all-reduce, overlapped with the rest of the backward pass: weight gradients complete
+                # in reverse arena order on the stream that runs the wgrad GEMMs, so every time a bucket (~32 MB) of the arena tail
+                # is final an async all-reduce of that contiguous range is queued behind them (RCCL syncs with that
+                # stream); allreduce_grads() later waits for the handles and reduces the small gamma/beta/bias range.
+                bucket_acc[0] += n.w_numel
+                if self.bucketed_allreduce and (bucket_acc[0] >= self.bucket_elems or n is first_wtrain):
+                    lo, hi = n.w_off, bucket_hi[0]
+                    seg.add_py(self._bucket_launcher(lo, hi, side))
+                    bucket_hi[0], bucket_acc[0] = lo, 0
+            if n.stem or n.src in self.input_tensors or not tgrad[n.src]:     # no gradient flows into the network inputs,
+                continue                                                       # nor below the last trainable parameter
             # data gradient into d:src
             dsrc, acc = grad_into(n.src, 0, can_alias=True)
             res_src = alias.pop(n.src) if n.src in alias else dsrc      # the skip gradient, still living in the block's dy
@@ -1567,26 +1669,30 @@ class YOLOV3(object):
         here the handles are awaited and the remaining small range (gamma, beta, head bias) is reduced."""
         if not self._dp_active():
             return
+        wt = [m.w_off for m in self.conv_nodes if self._node_trainable(m)[0]]
+        wt_lo = min(wt) if wt else self.n_weight             # frozen prefix (freeze_base): zeros, never reduced
         if self._pending_reduces:
             for h in self._pending_reduces:
                 h.wait()
             self._pending_reduces = []
             lo = self._reduced_from
             self._reduced_from = self.n_params
-            if lo > 0:                                   # anything before the first bucket (not expected)
-                torch.distributed.all_reduce(self.grads[:lo], group=self.process_group)
+            if lo > wt_lo:                               # anything before the first bucket (not expected)
+                torch.distributed.all_reduce(self.grads[wt_lo:lo], group=self.process_group)
             torch.distributed.all_reduce(self.grads[self.n_weight:], group=self.process_group)
         else:
-            torch.distributed.all_reduce(self.grads, group=self.process_group)
+            torch.distributed.all_reduce(self.grads[wt_lo:], group=self.process_group)
 
     def sgd_step(self, lr, momentum, wd, batch_size, no_wd=False):
-        """gluon.Trainer('sgd').step(batch_size) (train_yolov3.py:527-530,634); wd_mult=0 on gamma/beta/bias
-        with --no_wd (:495-497)."""
+        """gluon.Trainer('sgd').step(batch_size) (train_yolov3.py:527-530,634) over the trainable parameters only
+        (grad_req 'null' => no update and no weight decay, wrappers.py:55-57), with each parameter's lr_mult / wd_mult;
+        `no_wd=True` is shorthand for wd_mult = 0 on gamma / beta / bias (--no_wd, :495-497)."""
         rescale = self._grad_scale / float(batch_size)
         nw = self.n_weight
-        ops.sgd_momentum(self.weights[:nw], self.grads[:nw], self.momentum_buf[:nw], lr, momentum, wd, rescale)
-        ops.sgd_momentum(self.weights[nw:], self.grads[nw:], self.momentum_buf[nw:], lr, momentum,
-                         0.0 if no_wd else wd, rescale)
+        for lo, hi, lr_mult, wd_mult in self._optimizer_ranges():
+            wd_ = 0.0 if (no_wd and lo >= nw) else wd * wd_mult
+            ops.sgd_momentum(self.weights[lo:hi], self.grads[lo:hi], self.momentum_buf[lo:hi], lr * lr_mult, momentum,
+                             wd_, rescale)
         self._params_changed()
 
     # ------------------------------------------------------------------ checkpoints
@@ -1627,7 +1733,11 @@ def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs
         assert k == 5, "Currently only support t=5 but will increase to more later"        # yolo3_temporal.py:399
         assert block_conv_type in ('2', '3', '21')
         scope = (norm_kwargs or {}).get('scope', 'all') if norm_layer == 'syncbn' else None
-        return YOLOV3(classes, syncbn_scope=scope, k=k, block_conv_type=block_conv_type, temporal_out=True, **kwargs)
+        net = YOLOV3(classes, syncbn_scope=scope, k=k, block_conv_type=block_conv_type, temporal_out=True, **kwargs)
+        if freeze_base:
+            for name, p in net.collect_params('stages.*').items():
+                p.grad_req = 'null'
+        return net
     # yolo3.py:978-985
     if block_conv_type in ('3', '21'):
         assert k > 1, "k must be greater than 1 to use 3D or 2+1D convolutions"
@@ -1644,7 +1754,7 @@ def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs
         scope = (norm_kwargs or {}).get('scope', 'all')
     net = YOLOV3(classes, syncbn_scope=scope, k=k, k_join_type=k_join_type, k_join_pos=k_join_pos,
                  block_conv_type=block_conv_type, **kwargs)
-    if freeze_base:
+    if freeze_base:                          # wrappers.py:55-57: every Darknet parameter leaves the gradient / update
         for name, p in net.collect_params('stages.*').items():
             p.grad_req = 'null'
     return net
