@@ -26,6 +26,8 @@ import torch
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # split-operand fp32 products: 6 bf16 MFMAs per fp32 product block
+PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # two-way fp16 split: 3 f16 MFMAs per product block (f16 = bf16 rate)
+PEAKS = {"native": PEAK_FP32_MFMA_TFLOPS, "split": PEAK_SPLIT_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS}
 
 
 def parse():
@@ -233,24 +235,24 @@ def main():
                      "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)")
             math = None
         else:
-            # fp32 convolutions run in one of two product arithmetics, chosen per launch record by the plan-time
-            # autotuner: the fp32 MFMA (peak 157.3 TFLOP/s) or split operands (each fp32 value = 3 bf16 pieces, 6
-            # bf16 MFMAs per product block: peak = dense bf16 2500 / 6).  The roofline of the mix is the time an
-            # ideal machine needs, sum_i flops_i / peak_i; `peak` is the equivalent blended rate.
-            ideal_ms, math = 0.0, {"split": [0.0, 0.0, 0], "native": [0.0, 0.0, 0]}
+            # fp32 convolutions run in one of three product arithmetics, chosen per launch record by the plan-time
+            # autotuner: the fp32 MFMA (peak 157.3 TFLOP/s), the 3-way bf16 operand split (6 bf16 MFMAs per product
+            # block: peak = dense bf16 2500 / 6) or the 2-way fp16 split (3 f16 MFMAs: 2500 / 3).  The roofline of the mix
+            # is the time an ideal machine needs, sum_i flops_i / peak_i; `peak` is the equivalent blended rate.
+            ideal_ms, math = 0.0, {"f16x2": [0.0, 0.0, 0], "split": [0.0, 0.0, 0], "native": [0.0, 0.0, 0]}
             for fname, meta, e0, e1 in recs:
                 if fname != "vd_conv_igemm":
                     continue
-                sp = bool(meta.get("split"))
-                pk = PEAK_SPLIT_TFLOPS if sp else PEAK_FP32_MFMA_TFLOPS
-                ideal_ms += meta["flops"] / (pk * 1e12) * 1e3
-                m_ = math["split" if sp else "native"]
+                cls = "f16x2" if meta.get("f16x2") else ("split" if meta.get("split") else "native")
+                ideal_ms += meta["flops"] / (PEAKS[cls] * 1e12) * 1e3
+                m_ = math[cls]
                 m_[0] += meta["flops"]; m_[1] += e0.elapsed_time(e1); m_[2] += 1
             peak = ig[0] / (ideal_ms * 1e-3) / 1e12
-            kname = ("k_conv_igemm: fp32 in/out/accumulate; products as exact 3-way bf16 split x 6 v_mfma_f32_32x32x16_bf16 "
-                     "(%d launches) or v_mfma_f32_32x32x2_f32 (%d launches)" % (math["split"][2], math["native"][2]))
+            kname = ("k_conv_igemm: fp32 in/out/accumulate; products as a 2-way fp16 split x 3 v_mfma_f32_*_f16 (%d launches), "
+                     "an exact 3-way bf16 split x 6 v_mfma_f32_*_bf16 (%d launches) or v_mfma_f32_32x32x2_f32 (%d launches)"
+                     % (math["f16x2"][2], math["split"][2], math["native"][2]))
             math = {k_: {"launches": v[2], "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None,
-                         "ms": round(v[1], 3), "peak": PEAK_SPLIT_TFLOPS if k_ == "split" else PEAK_FP32_MFMA_TFLOPS}
+                         "ms": round(v[1], 3), "peak": round(PEAKS[k_], 1)}
                     for k_, v in math.items()}
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -310,8 +312,9 @@ def main():
                        "hip_graph": bool(a.graphs) and not train,
                        "fp32_math": (None if a.dtype == "bf16" else
                                      "VD_FP32_MATH=%s: tensors, accumulation and epilogues fp32; conv products on the fp32 "
-                                     "MFMA or as an exact 3-way bf16 operand split (6 bf16 MFMAs, dropped terms < 2^-23 of "
-                                     "the product; measured error vs fp64 <= the fp32 MFMA's), per launch by the autotuner"
+                                     "MFMA, as an exact 3-way bf16 operand split (6 bf16 MFMAs) or as a 2-way fp16 split "
+                                     "with per-tensor power-of-two scales (3 f16 MFMAs); measured error vs fp64 <= the "
+                                     "fp32 MFMA's for both; per launch by the autotuner"
                                      % os.environ.get("VD_FP32_MATH", "auto"))},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra, "phases": phases,
         }

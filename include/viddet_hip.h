@@ -46,6 +46,20 @@ extern "C" {
  * configs[4]; results are bf16-accurate (2^-8 per operand), NOT fp32-accurate.  Same kernels and tiles as VD_MATH_SPLIT. */
 #define VD_MATH_BF16     32
 
+/* VD_MATH_F16X2: each fp32 operand x is scaled by a per-tensor power of two s (exact) and split into two fp16 pieces,
+ * h = fp16(x*s), l = fp16(x*s - h) (round-to-nearest): 22-23 significand bits, |x*s - h - l| <= 2^-23 |x*s|.  A product is
+ * accumulated in fp32 from THREE partial products al*bh, ah*bl, ah*bh on the f16 matrix pipe (the dropped al*bl is below
+ * 2^-22 of the product) - half the matrix-pipe work of VD_MATH_SPLIT - and the epilogue multiplies by the inverse powers
+ * of two (exact).  The scale puts the tensor's max-abs in [2^14, 2^15): every element within 2^19 of it keeps full
+ * precision, smaller ones degrade gracefully towards an absolute floor of 2^-40 of the max.  The max-abs values are
+ * read from device memory (vd_conv_desc.amax_in / amax_w, vd_wgrad_desc.amax_in / amax_dout): VD_AMAX_SLOTS sub-slots,
+ * VD_AMAX_STRIDE floats apart, written by the producing kernels (atomic max; the caller zeroes them before the producer
+ * runs) or by vd_amax / vd_amax_segments.  Measured against fp64 the error is not above the fp32 MFMA's. */
+#define VD_MATH_F16X2    64
+#define VD_AMAX_SLOTS    32
+#define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
+#define VD_AMAX_FLOATS   (VD_AMAX_SLOTS * VD_AMAX_STRIDE)   /* floats per tensor */
+
 const char* vd_last_error(void);
 int vd_version(void);
 
@@ -103,6 +117,11 @@ typedef struct {
     const float* bs_invstd;
     float*  bs_part;
     float   bs_slope;
+    /* VD_MATH_F16X2: max-abs slots (VD_AMAX_FLOATS floats each) of `in` and of `wp`; required with that flag */
+    const float* amax_in;
+    const float* amax_w;
+    /* optional, any arithmetic: the epilogue publishes the max-abs of what it stores (zeroed by the caller) */
+    float*  amax_out;
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);
@@ -141,7 +160,9 @@ typedef struct {
     const float* in_scale;  /* optional in-load transform as in vd_conv_desc */
     const float* in_shift;
     float   in_slope;
-    int32_t flags;          /* VD_MATH_SPLIT: split-operand products (Co >= 64; narrower layers stay on the fp32 MFMA) */
+    int32_t flags;          /* VD_MATH_SPLIT / VD_MATH_F16X2: split-operand products (Co >= 64; narrower layers stay on the fp32 MFMA) */
+    const float* amax_in;   /* VD_MATH_F16X2: max-abs slots of `in` and of `dout` */
+    const float* amax_dout;
 } vd_wgrad_desc;
 
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d);
@@ -209,9 +230,10 @@ int vd_bn_finalize(const double* sums, double count, int C, const float* gamma, 
 int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                     const float* running_var, float eps, int C, float* scale, float* shift,
                     void* stream);
-/* y = leaky(x*scale+shift) (+ residual) */
+/* y = leaky(x*scale+shift) (+ residual); amax_out (optional): max-abs slots of y (VD_AMAX_FLOATS floats, zeroed by the
+ * caller) for the fp16 operand scale of the convs that read y (VD_MATH_F16X2) */
 int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, const float* residual,
-                      float* y, int64_t M, int C, float slope, void* stream);
+                      float* y, int64_t M, int C, float slope, float* amax_out, void* stream);
 /* backward, pass 1: partial sums of g=dy*leaky'(.) and g*xhat -> sums2[0..C)=sum g, [C..2C)=sum g*xhat */
 int vd_bn_bwd_reduce(const float* x, const float* dy, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, int64_t M, int C, float slope,
@@ -222,7 +244,16 @@ int vd_bn_param_grads(const double* sums2, int C, float* dgamma, float* dbeta, v
 int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift,
                     const float* save_mean, const float* save_invstd,
                     const double* sums2, double count, int64_t M, int C, float slope,
-                    float* dx, void* stream);
+                    float* dx, float* amax_out /* optional, as in vd_bn_apply_leaky */, void* stream);
+
+/* out[slot] = max(a[slot], b[slot]) over the sub-slots (b may be NULL: copy): the max-abs of a tensor assembled from, or
+ * bounded by, other tensors (upsample+concat, temporal pooling / stacking) without another pass over it */
+int vd_amax_merge(const float* a, const float* b, float* out, void* stream);
+/* max-abs of a tensor into its slots (zeroes them first): amax[VD_AMAX_FLOATS] */
+int vd_amax(const float* x, int64_t n, float* amax, void* stream);
+/* the same for `nseg` ranges of one buffer in ONE launch (the conv weights of the parameter arena, once per optimiser
+ * step): seg is a DEVICE array [nseg][2] = (element offset, element count); amax [nseg][VD_AMAX_FLOATS] */
+int vd_amax_segments(const float* base, const int64_t* seg, int nseg, float* amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pointwise helpers
@@ -292,6 +323,7 @@ int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M,
                          const float* weight_t, const float* class_t,
                          float ignore_thresh, int label_smooth,
                          float* losses, float* const dhead[3], float* box_out,
+                         float* const dhead_amax[3] /* optional: max-abs slots of the three gradients, zeroed by the caller */,
                          void* ws, int64_t ws_bytes, void* stream);
 int64_t vd_yolo_loss_ws_bytes(const vd_head_desc* h);
 

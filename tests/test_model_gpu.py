@@ -246,6 +246,61 @@ def test_data_parallel_two_ranks_equal_one_process():
         assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (dup, r.stdout[-800:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6)])
+def test_fp16_split_arithmetic_matches_oracle(cfg):
+    """set_conv_math('split2') (VD_MATH_F16X2: two fp16 pieces per operand, per-tensor power-of-two scales from the
+    producers' max-abs, three MFMAs per product block): the SAME tolerances as the fp32 arithmetics - heads 1e-3, identical
+    post-NMS rows, losses 2e-3, every one of the 222 gradients 5e-3 of its tensor's max - on the small fixture and on one
+    full 416x416 frame; and the launches really ran in it."""
+    from viddet_amd import model as M
+    from viddet_amd import lib as L
+    from tests.util import device_leaky_masks, check_masks_differ_only_at_ties, assert_rows_match, take_ranks
+    M.set_conv_math("split2")
+    M._TUNE_CACHE.clear()
+    try:
+        b, c, size, m = cfg
+        net, P = _mk_net(c, 6, obj_bias=-1.0)
+        rng = np.random.default_rng(6)
+        x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+        onet = ON.Net(P, c)
+        ids_r, sc_r, bx_r, rows_r, heads_r = onet.detect(x.astype(np.float64))
+        ids, sc, bx = net(dev(x))
+        torch.cuda.synchronize()
+        bufs = net._programs[('buf', b, size, size, False)]
+        for s_, hname in enumerate(net.head_names):
+            assert maxdiff(bufs[hname].cpu().numpy()[..., :3 * (5 + c)], np.moveaxis(heads_r[s_], 1, -1)) < 1e-3, s_
+        perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
+        assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 5e-3
+        used = [bool(a[0]._obj.flags & L.MATH_F16X2) for (fn_, _, a) in net._programs[('infer', b, size, size)][0].recs
+                if fn_ == 'vd_conv_igemm']
+        assert sum(used) >= 70, sum(used)
+        gt, tg = _targets(rng, b, c, size, m)
+        out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+        net.backward()
+        torch.cuda.synchronize()
+        used = [bool(a[0]._obj.flags & L.MATH_F16X2) for seg in net._last_train['fwd'] + net._last_train['bwd']
+                if hasattr(seg, 'recs') for (fn_, _, a) in seg.recs if fn_ in ('vd_conv_igemm', 'vd_conv_wgrad')]
+        assert sum(used) > 200, "the fp16-split arithmetic was not selected (%d launches)" % sum(used)
+        onet = ON.Net(P, c)
+        onet.mask_override = device_leaky_masks(net, net._last_train['bufs'])
+        losses_r, G, _ = onet.train_step(x.astype(np.float64), gt, *tg)
+        check_masks_differ_only_at_ties(onet.pre, onet.mask_override)
+        for i in range(4):
+            assert np.all(np.abs(out[i].cpu().numpy() - losses_r[i]) <= 2e-3 * np.maximum(1.0, np.abs(losses_r[i]))), i
+        worst = 0.0
+        for k, gref in G.items():
+            got = net.collect_params()[k].grad().cpu().numpy()
+            e = maxdiff(got, gref) / max(1e-3, float(np.abs(gref).max()))
+            worst = max(worst, e)
+            assert e < 5e-3, (k, e)
+        print("fp16-split arithmetic: worst gradient error / tensor max = %.2e" % worst)
+        for k, v in onet.new_running.items():
+            assert maxdiff(net.collect_params()[k].data().cpu().numpy(), v) < 1e-4, k
+    finally:
+        M.set_conv_math(None)
+        M._TUNE_CACHE.clear()
+
+
 def test_training_step_in_bf16_products():
     """set_conv_math('bf16'): convolution products on bf16-rounded operands, everything else fp32 (the mixed-precision
     training arithmetic of BASELINE configs[4]).  Losses within 3 % of the fp64 oracle's, gradients correlated to it."""

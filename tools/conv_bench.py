@@ -36,12 +36,18 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tile", type=int, default=0, help="forward/dgrad tile variant (0 = heuristic)")
     ap.add_argument("--split", action="store_true", help="split-operand fp32 products (VD_MATH_SPLIT)")
+    ap.add_argument("--math", default=None, choices=["native", "split", "f16x2", "bf16"],
+                    help="product arithmetic (overrides --split): f16x2 = two-way fp16 split (VD_MATH_F16X2)")
+    ap.add_argument("--only", default=None, help="comma list of shape indices")
     ap.add_argument("--check", action="store_true", help="print the max/rms error of the forward output against an fp64 CPU conv")
     a = ap.parse_args()
     B = a.batch
+    if a.math is not None:
+        a.split = {"native": False, "split": True, "f16x2": "f16x2", "bf16": "bf16"}[a.math]
     ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    shapes = SHAPES if a.only is None else [SHAPES[int(i)] for i in a.only.split(",")]
     print("%-28s %9s %9s %9s   (TFLOP/s; fp32 MFMA peak 157.3)" % ("layer", "fwd", "dgrad", "wgrad"))
-    for cin, cout, k, s, hin in SHAPES:
+    for cin, cout, k, s, hin in shapes:
         pad = k // 2
         ho = (hin + 2 * pad - k) // s + 1
         x = torch.randn(B, hin, hin, cin, device="cuda")

@@ -256,11 +256,12 @@ __global__ void k_bn_fold_eval(const float* __restrict__ gamma, const float* __r
 // sums converted) once per thread instead of once per element, and the 64-bit modulo leaves the loop.
 __global__ void k_bn_apply_leaky(const float* __restrict__ x, const float* __restrict__ scale,
                                  const float* __restrict__ shift, const float* __restrict__ res,
-                                 float* __restrict__ y, int64_t n4, int cvec, float slope) {
+                                 float* __restrict__ y, int64_t n4, int cvec, float slope, float* __restrict__ amax) {
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int col = (int)(i0 % cvec);
     const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
     const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
+    float amx = 0.f;
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         f32x4 o;
@@ -271,14 +272,16 @@ __global__ void k_bn_apply_leaky(const float* __restrict__ x, const float* __res
         }
         if (res) o += reinterpret_cast<const f32x4*>(res)[i];
         reinterpret_cast<f32x4*>(y)[i] = o;
+        amx = fmaxf(amx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
+    if (amax) vd_amax_publish(amax, amx);       // max-abs of the tensor for its consumers' fp16 operand scale
 }
 
 __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
                                const float* __restrict__ scale, const float* __restrict__ shift,
                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                const double* __restrict__ sums2, double count, int64_t n4, int C,
-                               float slope, float* __restrict__ dx) {
+                               float slope, float* __restrict__ dx, float* __restrict__ amax) {
     const int cvec = C >> 2;
     const float inv_count = (float)(1.0 / count);
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +296,7 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restr
         mg[e] = (float)sums2[col * 4 + e] * inv_count;
         mgx[e] = (float)sums2[C + col * 4 + e] * inv_count;
     }
+    float amx = 0.f;
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
@@ -305,7 +309,9 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restr
             o[e] = sc[e] * (g - mg[e] - xh * mgx[e]);
         }
         reinterpret_cast<f32x4*>(dx)[i] = o;
+        amx = fmaxf(amx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
+    if (amax) vd_amax_publish(amax, amx);
 }
 
 __global__ void k_bn_param_grads(const double* __restrict__ sums2, int C, float* __restrict__ dgamma,
@@ -443,11 +449,11 @@ int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_
 }
 
 int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, const float* residual, float* y,
-                      int64_t M, int C, float slope, void* stream) {
+                      int64_t M, int C, float slope, float* amax_out, void* stream) {
     VD_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && C % 4 == 0, "vd_bn_apply_leaky: bad args");
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(k_bn_apply_leaky, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                       residual, y, n4, C / 4, slope);
+                       residual, y, n4, C / 4, slope, amax_out);
     VD_CHECK_LAUNCH("vd_bn_apply_leaky");
     return VD_OK;
 }
@@ -482,12 +488,12 @@ int vd_bn_param_grads(const double* sums2, int C, float* dgamma, float* dbeta, v
 
 int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const float* shift, const float* save_mean,
                     const float* save_invstd, const double* sums2, double count, int64_t M, int C, float slope,
-                    float* dx, void* stream) {
+                    float* dx, float* amax_out, void* stream) {
     VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && dx && count > 0 && C % 4 == 0,
                "vd_bn_bwd_apply: bad args");
     const int64_t n4 = M * (C / 4);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
-                       save_mean, save_invstd, sums2, count, n4, C, slope, dx);
+                       save_mean, save_invstd, sums2, count, n4, C, slope, dx, amax_out);
     VD_CHECK_LAUNCH("vd_bn_bwd_apply");
     return VD_OK;
 }

@@ -40,3 +40,39 @@ __device__ __forceinline__ int vd_xcd_remap(int bid, int nblk) {
 
 // accurate expf (not __expf): decoded boxes are compared with the fp64 oracle at 1e-3 px
 __device__ __forceinline__ float vd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- per-tensor max-abs ("amax") exchange between producer and consumer kernels (VD_MATH_F16X2, viddet_hip.h) ----
+// A tensor's amax lives in VD_AMAX_SLOTS sub-slots, VD_AMAX_STRIDE floats (256 B) apart, so that the thousands of
+// workgroups of a streaming producer do not queue their atomics on one address; the tensor's amax is the maximum of
+// the sub-slots.  Values are non-negative floats, so unsigned-integer max on the bit patterns is float max; the
+// caller zeroes the slots before the producer runs.
+__device__ __forceinline__ float vd_wave_max(float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    return m;
+}
+
+// every lane of the wave calls with its own running max (>= 0); one atomic per wave
+__device__ __forceinline__ void vd_amax_publish(float* amax, float m) {
+    m = vd_wave_max(m);
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(amax + (size_t)(blockIdx.x & (VD_AMAX_SLOTS - 1)) * VD_AMAX_STRIDE),
+                  __float_as_uint(m));
+}
+
+// wave-uniform amax of a tensor (all 64 lanes call)
+__device__ __forceinline__ float vd_amax_read(const float* amax) {
+    const int lane = threadIdx.x & 63;
+    float v = lane < VD_AMAX_SLOTS ? amax[(size_t)lane * VD_AMAX_STRIDE] : 0.f;
+    v = vd_wave_max(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// exponent e with amax * 2^e in [2^14, 2^15): the top of the fp16 range with a factor 2 of headroom below 65504.
+// amax == 0 / denormal / inf / nan -> 0 (no scaling).
+__device__ __forceinline__ int vd_f16_scale_exp(float amax) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    if (E == 0 || E == 255) return 0;
+    const int e = 141 - E;                  // 14 - (E - 127)
+    return e > 126 ? 126 : e;
+}

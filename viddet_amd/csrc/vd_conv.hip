@@ -70,6 +70,9 @@ __device__ unsigned long long g_stamps_f32[16];
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));      // one 16-byte MFMA operand (8 bf16 or 8 fp16), type-agnostic
 
 // ---- split-operand fp32 math (VD_MATH_SPLIT) -------------------------------------------------------------
 // x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (round-to-nearest, the subtractions are
@@ -103,6 +106,50 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& h, uint2& m, uint2&
     h = make_uint2(hh[0], hh[1]); m = make_uint2(mm[0], mm[1]); l = make_uint2(ll[0], ll[1]);
 }
 
+// ---- two-way fp16 split (VD_MATH_F16X2) ---------------------------------------------------------------------
+// With s the tensor's power-of-two scale (amax*s in [2^14, 2^15)): h = fp16(x*s), l = fp16(x*s - h), both round-to-
+// nearest; x*s - h is exact in fp32.  A product is accumulated from al*bh, ah*bl, ah*bh (f16 MFMAs, fp32 accumulate);
+// al*bl < 2^-22 |a*b| is dropped.  LDS rows hold the two planes back to back, [h: 32 fp16][l: 32] = 128 B = eight 16-B
+// slots s = 4*plane + chunk, stored at slot s ^ key(row) with key(row) = ((row >> 1) & 7) ^ ((row & 1) << 2): the 16 rows
+// of every ds_read_b128 lane group (both MFMA operand maps) then fall on 16 distinct slots of the 64 banks, and the two
+// rows of a ds_write_b64 lane group on the two halves of the 32 write banks - conflict-free without padding.
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    f32x2 v = {a, b};
+    f16x2 r = __builtin_convertvector(v, f16x2);        // v_cvt_pk_f16_f32 (RNE) on gfx950
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ void split2(const f32x4 v, const float s, uint2& h, uint2& l) {
+    unsigned hh[2], ll[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = v[2 * q] * s, x1 = v[2 * q + 1] * s;
+        const unsigned hp = pk_f16(x0, x1);
+        const f16x2 hv = __builtin_bit_cast(f16x2, hp);
+        hh[q] = hp;
+        ll[q] = pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+    }
+    h = make_uint2(hh[0], hh[1]); l = make_uint2(ll[0], ll[1]);
+}
+
+__device__ __forceinline__ int f16x2_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
+
+template <int NPL>
+__device__ __forceinline__ f32x16 mfma32(const v4i a, const v4i b, const f32x16 c) {
+    if (NPL == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int NPL>
+__device__ __forceinline__ f32x4 mfma16(const v4i a, const v4i b, const f32x4 c) {
+    if (NPL == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// partial products of one block, smallest first: plane indices of the A and B operands
+template <int NPL> struct Terms;
+template <> struct Terms<3> { static constexpr int N = 6; static constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0}; };
+template <> struct Terms<2> { static constexpr int N = 3; static constexpr int QA[6] = {1, 0, 0, 0, 0, 0}, QB[6] = {0, 1, 0, 0, 0, 0}; };
+template <> struct Terms<1> { static constexpr int N = 1; static constexpr int QA[6] = {0, 0, 0, 0, 0, 0}, QB[6] = {0, 0, 0, 0, 0, 0}; };
+
 // n / d for d >= 1 with rcp = 0xFFFFFFFF / d + 1: the multiply-high overshoots the quotient by at most one
 __device__ __forceinline__ unsigned udiv_rcp(unsigned n, unsigned d, unsigned rcp) {
     unsigned q = d == 1u ? n : __umulhi(n, rcp);
@@ -132,9 +179,10 @@ struct RowInfo {
 // 1 = only the leading piece, ONE bf16 MFMA per product block (VD_MATH_BF16: bf16-rounded operands, fp32 accumulate).
 template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3>
 __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
-    static_assert(NPL == 3 || (NPL == 1 && SP), "planes");
-    constexpr int SP_ROWB = NPL * 64;          // LDS row of the split arithmetic: NPL planes of 32 bf16
-    constexpr int NTERM = NPL == 3 ? 6 : 1;
+    static_assert(NPL == 3 || ((NPL == 1 || NPL == 2) && SP), "planes");
+    static_assert(NPL != 2 || !XF, "the fp16 split needs the max-abs of the operand it splits: no in-load transform");
+    constexpr int SP_ROWB = NPL * 64;          // LDS row of the split arithmetic: NPL planes of 32 bf16 (fp16 for NPL == 2)
+    constexpr int NTERM = Terms<NPL>::N;
     static_assert(!M16 || SP, "the 16x16x32 shape exists for the bf16 operands of the split arithmetic");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
@@ -162,6 +210,17 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 
     const int lrow = tid >> 3;
     const int lc4 = (tid & 7) * 4;
+
+    // NPL == 2: power-of-two operand scales from the tensors' max-abs (vd_common.h); requested first, used by the first
+    // LDS store, so the two loads hide behind the row geometry
+    int sexp_a = 0, sexp_b = 0;
+    float scl_a = 1.f, scl_b = 1.f;
+    if (NPL == 2) {
+        sexp_a = vd_f16_scale_exp(vd_amax_read(p.amax_in));
+        sexp_b = vd_f16_scale_exp(vd_amax_read(p.amax_w));
+        scl_a = __uint_as_float((unsigned)(127 + sexp_a) << 23);
+        scl_b = __uint_as_float((unsigned)(127 + sexp_b) << 23);
+    }
 
     STAMP(0);
     // Row geometry (M < 2^31, checked on the host).  The tap table sits in lane registers (lane t = tap t, read back
@@ -281,6 +340,31 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 #endif
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
+        if (SP && NPL == 2) {
+            const int key = f16x2_key(lrow);              // lrow + RPP * i has the same low four bits (RPP = 32 or 64)
+            const int c = (tid & 7) >> 1, half = (tid & 1) << 3;
+            const int oh = ((c ^ key) << 4) + half, ol = (((4 + c) ^ key) << 4) + half;
+            char* a3 = As3 + buf * BM * SP_ROWB;
+            char* b3 = Bs3 + buf * BN * SP_ROWB;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                uint2 h, l;
+                split2(ra[i], scl_a, h, l);
+                char* r = a3 + (lrow + RPP * i) * SP_ROWB;
+                *reinterpret_cast<uint2*>(r + oh) = h;
+                *reinterpret_cast<uint2*>(r + ol) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                if (BHALF && lrow >= BN) break;           // wave-uniform: these lanes hold no weight row
+                uint2 h, l;
+                split2(rb[i], scl_b, h, l);
+                char* r = b3 + (lrow + RPP * i) * SP_ROWB;
+                *reinterpret_cast<uint2*>(r + oh) = h;
+                *reinterpret_cast<uint2*>(r + ol) = l;
+            }
+            return;
+        }
         if (SP) {
             // swizzled slot + half; key = row bits 2..3 for the 32-row operand map, 2 * row bit 3 for the 16-row one
             // (both make the 16 rows of every ds_read_b128 lane group hit 16 distinct slots)
@@ -329,21 +413,22 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     auto compute = [&](int buf) {
         if (SP && M16) {
             const int r16 = lane & 15, ch = lane >> 4;              // operand row within a 16-row block, 8-k chunk
-            const int rkey = 2 * ((r16 >> 3) & 1);
-            const char* a3 = As3 + (buf * BM + wm * TM * 32 + r16) * SP_ROWB + ((ch ^ rkey) << 4);
-            const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + r16) * SP_ROWB + ((ch ^ rkey) << 4);
-            bf16x8 fa[2 * TM][NPL];
+            const int rkey = NPL == 2 ? f16x2_key(r16) : 2 * ((r16 >> 3) & 1);
+            // byte offset of plane q's chunk `ch` inside a row
+            auto slot = [&](int q) { return NPL == 2 ? (((4 * q + ch) ^ rkey) << 4) : (q * 64 + ((ch ^ rkey) << 4)); };
+            const char* a3 = As3 + (buf * BM + wm * TM * 32 + r16) * SP_ROWB;
+            const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + r16) * SP_ROWB;
+            v4i fa[2 * TM][NPL];
 #pragma unroll
             for (int mb = 0; mb < 2 * TM; ++mb)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q)
-                    fa[mb][q] = *reinterpret_cast<const bf16x8*>(a3 + mb * 16 * SP_ROWB + q * 64);
-            constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
+                    fa[mb][q] = *reinterpret_cast<const v4i*>(a3 + mb * 16 * SP_ROWB + slot(q));
 #pragma unroll
             for (int nb = 0; nb < 2 * TN; ++nb) {
-                bf16x8 fb[NPL];
+                v4i fb[NPL];
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(b3 + nb * 16 * SP_ROWB + q * 64);
+                for (int q = 0; q < NPL; ++q) fb[q] = *reinterpret_cast<const v4i*>(b3 + nb * 16 * SP_ROWB + slot(q));
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -354,7 +439,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                     f32x4 c = {A_[e0], A_[e0 + 1], A_[e0 + 2], A_[e0 + 3]};
 #pragma unroll
                     for (int t = 0; t < NTERM; ++t)
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb][NPL == 3 ? QA[t] : 0], fb[NPL == 3 ? QB[t] : 0], c, 0, 0, 0);
+                        c = mfma16<NPL>(fa[mb][Terms<NPL>::QA[t]], fb[Terms<NPL>::QB[t]], c);
                     A_[e0] = c[0]; A_[e0 + 1] = c[1]; A_[e0 + 2] = c[2]; A_[e0 + 3] = c[3];
                 }
 #if VD_SETPRIO
@@ -366,21 +451,21 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         if (SP) {
             const char* a3 = As3 + (buf * BM + wm * TM * 32 + (lane & 31)) * SP_ROWB;
             const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + (lane & 31)) * SP_ROWB;
-            const int swz = (lane >> 2) & 3, hh = lane >> 5;
+            const int swz = NPL == 2 ? f16x2_key(lane & 31) : ((lane >> 2) & 3), hh = lane >> 5;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                bf16x8 fa[TM][NPL], fb[TN][NPL];
+                v4i fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
+                    const int so = NPL == 2 ? (((4 * q + kc * 2 + hh) ^ swz) << 4) : (q * 64 + (((kc * 2 + hh) ^ swz) << 4));
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        fa[mi][q] = *reinterpret_cast<const bf16x8*>(a3 + mi * 32 * SP_ROWB + q * 64 + (((kc * 2 + hh) ^ swz) << 4));
+                        fa[mi][q] = *reinterpret_cast<const v4i*>(a3 + mi * 32 * SP_ROWB + so);
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        fb[ni][q] = *reinterpret_cast<const bf16x8*>(b3 + ni * 32 * SP_ROWB + q * 64 + (((kc * 2 + hh) ^ swz) << 4));
+                        fb[ni][q] = *reinterpret_cast<const v4i*>(b3 + ni * 32 * SP_ROWB + so);
                 }
-                // smallest partial products first
-                constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
+                // smallest partial products first (Terms<NPL>)
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -390,9 +475,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][NPL == 3 ? QA[t] : 0],
-                                                                                  fb[ni][NPL == 3 ? QB[t] : 0],
-                                                                                  acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = mfma32<NPL>(fa[mi][Terms<NPL>::QA[t]], fb[ni][Terms<NPL>::QB[t]], acc[mi][ni]);
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -475,6 +558,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     }
 
     STAMP(4);
+    if (NPL == 2) {                    // undo the two operand scales: an exact power of two
+        const int de = -(sexp_a + sexp_b);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], de);
+    }
     // ---- epilogue -----------------------------------------------------------------------
     // The C/D layout has a column per lane and rows across registers: stored directly, one instruction writes two
     // 128-B row segments of 4 B per lane.  Each wave instead transposes one 32x32 accumulator tile at a time through
@@ -492,6 +584,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
         for (int e = 0; e < 4; ++e) bs1[ni][e] = bs2[ni][e] = 0.f;
+    float amx = 0.f;                                    // max-abs of what this lane stores (p.amax_out)
     // float4 path: rows 16-B aligned (wave-uniform; every tensor of the model qualifies, odd pitches fall back)
     const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) &&
                         (!(p.flags & VD_EPI_RESIDUAL) || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 16 == 0)));
@@ -579,7 +672,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                     for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * p.slope;
                 }
                 if (has_res) t += rres[b & S1][i];
-                if (ok) *reinterpret_cast<f32x4*>(p.out + ropix[b & S1][i] * p.ldo + colv[ni]) = t;
+                if (ok) {
+                    *reinterpret_cast<f32x4*>(p.out + ropix[b & S1][i] * p.ldo + colv[ni]) = t;
+                    amx = fmaxf(amx, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))));
+                }
                 if (BS && bstat) {
                     const f32x4 z = rz[BS ? (b & S1) : 0][i];
 #pragma unroll
@@ -655,6 +751,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                 if (nvalid >= 4 && vec_ok) {
                     if (p.flags & VD_EPI_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.residual + opix * p.ldr + col);
                     *reinterpret_cast<f32x4*>(dst) = v;
+                    amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                     if (bstat) {
                         const f32x4 z = *reinterpret_cast<const f32x4*>(p.bs_z + opix * p.ldo + col);
 #pragma unroll
@@ -672,6 +769,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                             float t = v[e];
                             if (p.flags & VD_EPI_RESIDUAL) t += p.residual[opix * p.ldr + col + e];
                             dst[e] = t;
+                            amx = fmaxf(amx, fabsf(t));
                             if (bstat) {
                                 const float z = p.bs_z[opix * p.ldo + col + e];
                                 const float u = z * qsc[e] + qsh[e];
@@ -687,6 +785,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 
     }
     STAMP(5);
+    if (p.amax_out) vd_amax_publish(p.amax_out, amx);
     // ---- fused BatchNorm backward reductions: a lane holds 4 columns x (4 rows x TM tiles); fold the 8 row groups of
     // the wave (lane bits 3..5), then the WM waves that share the columns, one writer per (tile_m, column)
     if (bstat) {
@@ -815,6 +914,10 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
         if (d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, SP ? 1 : 3>(d, s);
         return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 1 : 3>(d, s);
     }
+    if (SP && (d.flags & VD_MATH_F16X2)) {         // two fp16 planes, three MFMAs per product block; no XF variant
+        if (d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, SP ? 2 : 3>(d, s);
+        return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 2 : 3>(d, s);
+    }
     if (!XF && d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, 3>(d, s);
     return launch_igemm_bs<WM, WN, TM, TN, XF, SP, M16, false, 3>(d, s);
 }
@@ -884,7 +987,7 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
 
 template <bool XF>
 int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
-    if (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16)) return dispatch_igemm_split<XF>(d, s);
+    if (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) return dispatch_igemm_split<XF>(d, s);
     const int tile = igemm_resolve_tile(d);
     switch (tile) {
         case 1: return launch_igemm<2, 2, 2, 2, XF>(d, s);   // 128 x 128, 4 waves of 64x64
@@ -955,9 +1058,18 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     constexpr int APL = WG_BP * BM * 2, BPL = WG_BP * WG_BN * 2;      // bytes of one plane
     char* As3 = reinterpret_cast<char*>(smem);
     char* Bs3 = As3 + 2 * NPL * APL;
-    constexpr int NTERM = NPL == 3 ? 6 : 1;
+    constexpr int NTERM = Terms<NPL>::N;
+    static_assert(NPL != 2 || !XF, "no in-load transform in the fp16 split");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    int sexp_a = 0, sexp_b = 0;               // NPL == 2: operand scales from the tensors' max-abs (A = dout, B = in)
+    float scl_a = 1.f, scl_b = 1.f;
+    if (NPL == 2) {
+        sexp_a = vd_f16_scale_exp(vd_amax_read(p.amax_dout));
+        sexp_b = vd_f16_scale_exp(vd_amax_read(p.amax_in));
+        scl_a = __uint_as_float((unsigned)(127 + sexp_a) << 23);
+        scl_b = __uint_as_float((unsigned)(127 + sexp_b) << 23);
+    }
     const int Ktot = p.T * p.Ci;
     const int jtiles = (Ktot + WG_BN - 1) / WG_BN;
     const int mtiles = (p.Co + BM - 1) / BM;
@@ -1080,6 +1192,9 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                     split3(ra[i], h, m, l);
                     *reinterpret_cast<uint2*>(r + APL) = m;
                     *reinterpret_cast<uint2*>(r + 2 * APL) = l;
+                } else if (NPL == 2) {
+                    split2(ra[i], scl_a, h, l);
+                    *reinterpret_cast<uint2*>(r + APL) = l;
                 } else {
                     h = make_uint2(pk_bf16(ra[i][0], ra[i][1]), pk_bf16(ra[i][2], ra[i][3]));
                 }
@@ -1094,6 +1209,9 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                     split3(rb[i], h, m, l);
                     *reinterpret_cast<uint2*>(r + BPL) = m;
                     *reinterpret_cast<uint2*>(r + 2 * BPL) = l;
+                } else if (NPL == 2) {
+                    split2(rb[i], scl_b, h, l);
+                    *reinterpret_cast<uint2*>(r + BPL) = l;
                 } else {
                     h = make_uint2(pk_bf16(rb[i][0], rb[i][1]), pk_bf16(rb[i][2], rb[i][3]));
                 }
@@ -1114,26 +1232,23 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const char* b3 = Bs3 + buf * NPL * BPL;
 #pragma unroll
             for (int kc = 0; kc < WG_BP / 16; ++kc) {
-                bf16x8 fa[TM][NPL], fb[TN][NPL];
+                v4i fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        fa[mi][q] = tr_operand(a3 + q * APL, BM * 2, wm * TM * 32 + mi * 32, kc, lane);
+                        fa[mi][q] = __builtin_bit_cast(v4i, tr_operand(a3 + q * APL, BM * 2, wm * TM * 32 + mi * 32, kc, lane));
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
-                        fb[ni][q] = tr_operand(b3 + q * BPL, WG_BN * 2, wn * TN * 32 + ni * 32, kc, lane);
+                        fb[ni][q] = __builtin_bit_cast(v4i, tr_operand(b3 + q * BPL, WG_BN * 2, wn * TN * 32 + ni * 32, kc, lane));
                 }
-                constexpr int QA[6] = {1, 2, 0, 1, 0, 0}, QB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t)
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][NPL == 3 ? QA[t] : 0],
-                                                                                  fb[ni][NPL == 3 ? QB[t] : 0],
-                                                                                  acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = mfma32<NPL>(fa[mi][Terms<NPL>::QA[t]], fb[ni][Terms<NPL>::QB[t]], acc[mi][ni]);
             }
             return;
         }
@@ -1189,6 +1304,15 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
         }
     }
 
+    if (NPL == 2) {                    // undo the two operand scales: an exact power of two
+        const int de = -(sexp_a + sexp_b);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], de);
+    }
     float* out = dst + (int64_t)split * p.Co * Ktot;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
@@ -1225,7 +1349,7 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
-bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16)) && d.Co >= 64; }
+bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) && d.Co >= 64; }
 int wgrad_bm(const vd_wgrad_desc& d) {
     if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : (d.Co >= 128 ? 128 : 64);
     return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
@@ -1273,15 +1397,15 @@ void launch_wgrad_n(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps,
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, false, SP, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, true, SP, NPL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<WM, WN, TM, TN, (NPL != 2), SP, NPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const int64_t tiles = vd_cdiv(d.Co, BM) * vd_cdiv((int64_t)d.T * d.Ci, WG_BN);
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_do = zp - d.dout;
-    if (d.in_scale)
-        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, true, SP, NPL>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds,
+    if (d.in_scale && NPL != 2)
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, (NPL != 2), SP, NPL>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds,
                            s, d, dst, splits, pps, zd_in, zd_do);
     else
         hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, false, SP, NPL>), dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds,
@@ -1291,6 +1415,7 @@ void launch_wgrad_n(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps,
 template <int WM, int WN, int TM, int TN, bool SP = false>
 void launch_wgrad(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
     if (SP && (d.flags & VD_MATH_BF16)) launch_wgrad_n<WM, WN, TM, TN, SP, SP ? 1 : 3>(d, dst, splits, pps, s);
+    else if (SP && (d.flags & VD_MATH_F16X2)) launch_wgrad_n<WM, WN, TM, TN, SP, SP ? 2 : 3>(d, dst, splits, pps, s);
     else launch_wgrad_n<WM, WN, TM, TN, SP, 3>(d, dst, splits, pps, s);
 }
 
@@ -1408,6 +1533,8 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(!d->bs_part || (!d->stats_part && !d->in_scale && d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd &&
                                d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg),
                "vd_conv_igemm: fused BN backward reductions need direct output geometry and all five bs_* inputs");
+    VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || (d->amax_in && d->amax_w && !d->in_scale),
+               "vd_conv_igemm: VD_MATH_F16X2 needs amax_in and amax_w (and no in-load transform)");
     hipStream_t s = (hipStream_t)stream;
     if (d->in_scale) dispatch_igemm<true>(*d, s);
     else dispatch_igemm<false>(*d, s);
@@ -1418,7 +1545,7 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
 int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
     if (!d) return 0;
     const int64_t M = (int64_t)d->N * d->Hg * d->Wg;
-    if (d->flags & (VD_MATH_SPLIT | VD_MATH_BF16)) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
+    if (d->flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
     return (int)vd_cdiv(M, igemm_tile_bm(igemm_resolve_tile(*d)));
 }
 
@@ -1435,6 +1562,8 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_wgrad: bad Kfr");
     VD_REQUIRE(d->ldd >= d->Co && d->ldd % 4 == 0, "vd_conv_wgrad: bad ldd");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_wgrad: in_scale/in_shift mismatch");
+    VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || d->Co < 64 || (d->amax_in && d->amax_dout && !d->in_scale),
+               "vd_conv_wgrad: VD_MATH_F16X2 needs amax_in and amax_dout (and no in-load transform)");
     VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31) && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31),
                "vd_conv_wgrad: pixel count overflows int32");
     const int splits = wgrad_pick_splits(*d);

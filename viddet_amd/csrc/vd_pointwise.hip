@@ -36,6 +36,35 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
     if (t < n) o[t] = a[t] + b[t];
 }
 
+// max-abs of x[0..n) into the tensor's amax sub-slots (vd_common.h); float4 body + scalar tail
+__device__ __forceinline__ float amax_range(const float* __restrict__ x, int64_t n, int64_t first, int64_t stride) {
+    float m = 0.f;
+    const int64_t n4 = ((uintptr_t)x % 16 == 0) ? n / 4 : 0;
+    for (int64_t i = first; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    for (int64_t i = n4 * 4 + first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+    return m;
+}
+
+__global__ void k_amax(const float* __restrict__ x, int64_t n, float* __restrict__ amax) {
+    vd_amax_publish(amax, amax_range(x, n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x));
+}
+
+// blockIdx.y = segment; seg[2*s] = element offset, seg[2*s+1] = element count
+__global__ void k_amax_segments(const float* __restrict__ base, const int64_t* __restrict__ seg, float* __restrict__ amax) {
+    const int sgm = blockIdx.y;
+    const float* x = base + seg[2 * sgm];
+    vd_amax_publish(amax + (size_t)sgm * VD_AMAX_FLOATS,
+                    amax_range(x, seg[2 * sgm + 1], (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x));
+}
+
+__global__ void k_amax_merge(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const int i = threadIdx.x * VD_AMAX_STRIDE;
+    out[i] = b ? fmaxf(a[i], b[i]) : a[i];
+}
+
 __global__ void k_fill(float* __restrict__ o, float v, int64_t n) {
     GRID_STRIDE(i, n) o[i] = v;
 }
@@ -205,6 +234,39 @@ int vd_fill(float* out, float v, int64_t n, void* stream) {
     VD_REQUIRE(out && n > 0, "vd_fill: bad args");
     hipLaunchKernelGGL(k_fill, dim3(sblocks(n)), dim3(256), 0, (hipStream_t)stream, out, v, n);
     VD_CHECK_LAUNCH("vd_fill");
+    return VD_OK;
+}
+
+int vd_amax(const float* x, int64_t n, float* amax, void* stream) {
+    VD_REQUIRE(x && amax && n > 0, "vd_amax: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, sizeof(float) * VD_AMAX_FLOATS, s) != hipSuccess) {
+        vd_set_error("vd_amax: memset failed");
+        return VD_ELAUNCH;
+    }
+    int nb = sblocks(n / 4 + 1);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_amax, dim3(nb), dim3(256), 0, s, x, n, amax);
+    VD_CHECK_LAUNCH("vd_amax");
+    return VD_OK;
+}
+
+int vd_amax_segments(const float* base, const int64_t* seg, int nseg, float* amax, void* stream) {
+    VD_REQUIRE(base && seg && amax && nseg > 0 && nseg < 65536, "vd_amax_segments: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, sizeof(float) * VD_AMAX_FLOATS * (size_t)nseg, s) != hipSuccess) {
+        vd_set_error("vd_amax_segments: memset failed");
+        return VD_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_amax_segments, dim3(32, nseg), dim3(256), 0, s, base, seg, amax);
+    VD_CHECK_LAUNCH("vd_amax_segments");
+    return VD_OK;
+}
+
+int vd_amax_merge(const float* a, const float* b, float* out, void* stream) {
+    VD_REQUIRE(a && out, "vd_amax_merge: bad args");
+    hipLaunchKernelGGL(k_amax_merge, dim3(1), dim3(VD_AMAX_SLOTS), 0, (hipStream_t)stream, a, b, out);
+    VD_CHECK_LAUNCH("vd_amax_merge");
     return VD_OK;
 }
 

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
                                                    const float* __restrict__ weight_t,
                                                    const float* __restrict__ class_t, float ignore_thresh,
                                                    int label_smooth, float* dh0, float* dh1, float* dh2,
-                                                   float* __restrict__ box_out, float* __restrict__ part) {
+                                                   float* __restrict__ box_out, float* __restrict__ part,
+                                                   float* am0, float* am1, float* am2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float sgt[LOSS_MAX_GT * 4];
     __shared__ float sred[4][4];
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
     for (int i = threadIdx.x; i < M * 4; i += blockDim.x) sgt[i] = gt[(int64_t)b * M * 4 + i];
     __syncthreads();
     float l_obj = 0.f, l_ctr = 0.f, l_scl = 0.f, l_cls = 0.f;
+    float amx0 = 0.f, amx1 = 0.f, amx2 = 0.f;   // max-abs of the gradients this lane writes, per scale
     const float sw = fminf(1.0f / (float)C, 1.0f / 40.0f);
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         int s, pix, pbase;
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
             aux[a * 8 + 6] = objness;
         }
         WAVE_SYNC();
+        float amx_r = 0.f;
         for (int a = 0; a < 3; ++a) {
             const bool mask = aux[a * 8 + 5] > 0.f;
             const float objness = aux[a * 8 + 6];
@@ -422,10 +425,19 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
                     gv = (vd_sigmoid(x) - t) * cm;
                 }
                 dst[a * npred + j] = gv;
+                amx_r = fmaxf(amx_r, fabsf(gv));
             }
         }
         for (int e = A + lane; e < h.ldh; e += 64) dst[e] = 0.f;
+        if (s == 0) amx0 = fmaxf(amx0, amx_r);
+        else if (s == 1) amx1 = fmaxf(amx1, amx_r);
+        else amx2 = fmaxf(amx2, amx_r);
         WAVE_SYNC();
+    }
+    if (am0) {
+        vd_amax_publish(am0, amx0);
+        vd_amax_publish(am1, amx1);
+        vd_amax_publish(am2, amx2);
     }
     // block reduction of the four partial losses (fixed order => deterministic)
     float v[4] = {l_obj, l_ctr, l_scl, l_cls};
@@ -520,12 +532,13 @@ int64_t vd_yolo_loss_ws_bytes(const vd_head_desc* h) {
 
 int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
                          const float* scale_t, const float* weight_t, const float* class_t, float ignore_thresh,
-                         int label_smooth, float* losses, float* const dhead[3], float* box_out, void* ws,
-                         int64_t ws_bytes, void* stream) {
+                         int label_smooth, float* losses, float* const dhead[3], float* box_out,
+                         float* const dhead_amax[3], void* ws, int64_t ws_bytes, void* stream) {
     VD_REQUIRE(head_ok(h), "vd_yolo_loss_fwd_bwd: bad head descriptor");
     VD_REQUIRE(obj_t && center_t && scale_t && weight_t && class_t && losses && dhead && dhead[0] && dhead[1] && dhead[2],
                "vd_yolo_loss_fwd_bwd: null pointer");
     VD_REQUIRE(M >= 0 && M <= LOSS_MAX_GT && (M == 0 || gt), "vd_yolo_loss_fwd_bwd: M=%d outside [0,%d]", M, LOSS_MAX_GT);
+    VD_REQUIRE(!dhead_amax || (dhead_amax[0] && dhead_amax[1] && dhead_amax[2]), "vd_yolo_loss_fwd_bwd: dhead_amax needs three slots");
     const int nb = loss_blocks(h);
     const int64_t need = (int64_t)h->B * nb * 4 * (int64_t)sizeof(float);
     if (!ws || ws_bytes < need) {
@@ -537,7 +550,9 @@ int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const fl
     VD_REQUIRE(lds <= 48 * 1024, "vd_yolo_loss_fwd_bwd: too many classes for the LDS row stage");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_yolo_loss, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t,
-                       class_t, ignore_thresh, label_smooth, dhead[0], dhead[1], dhead[2], box_out, (float*)ws);
+                       class_t, ignore_thresh, label_smooth, dhead[0], dhead[1], dhead[2], box_out, (float*)ws,
+                       dhead_amax ? dhead_amax[0] : nullptr, dhead_amax ? dhead_amax[1] : nullptr,
+                       dhead_amax ? dhead_amax[2] : nullptr);
     VD_CHECK_LAUNCH("vd_yolo_loss_fwd_bwd");
     hipLaunchKernelGGL(k_loss_finalize, dim3((unsigned)vd_cdiv(h->B * 4, 64)), dim3(64), 0, s, (const float*)ws, nb, losses,
                        h->B);

@@ -14,6 +14,9 @@ VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
 MATH_BF16 = 32         # products on bf16-rounded operands (one MFMA term), fp32 tensors and accumulation
+MATH_F16X2 = 64        # two-way fp16 operand split with per-tensor power-of-two scales (three MFMA terms, fp32-accurate)
+AMAX_SLOTS, AMAX_STRIDE = 32, 64
+AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 
 _fp = C.c_void_p
 
@@ -32,6 +35,7 @@ class ConvDesc(C.Structure):
         ("stats_part", _fp),
         ("bs_z", _fp), ("bs_scale", _fp), ("bs_shift", _fp), ("bs_mean", _fp), ("bs_invstd", _fp), ("bs_part", _fp),
         ("bs_slope", C.c_float),
+        ("amax_in", _fp), ("amax_w", _fp), ("amax_out", _fp),
     ]
 
 
@@ -44,6 +48,7 @@ class WgradDesc(C.Structure):
         ("dy", C.c_int32 * VD_MAX_TAPS), ("dx", C.c_int32 * VD_MAX_TAPS), ("dz", C.c_int32 * VD_MAX_TAPS),
         ("Kfr", C.c_int32), ("splits", C.c_int32),
         ("in_scale", _fp), ("in_shift", _fp), ("in_slope", C.c_float), ("flags", C.c_int32),
+        ("amax_in", _fp), ("amax_dout", _fp),
     ]
 
 
@@ -79,10 +84,13 @@ SIGNATURES = {
     "vd_bn_sum_finalize": (_i, [_p, _i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "vd_bn_sum_param_grads": (_i, [_p, _i, _i, _p, _p, _p, _p, _i64, _p]),
     "vd_bn_fold_eval": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
-    "vd_bn_apply_leaky": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "vd_bn_apply_leaky": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p, _p]),
     "vd_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "vd_bn_param_grads": (_i, [_p, _i, _p, _p, _p]),
-    "vd_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p]),
+    "vd_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p, _p]),
+    "vd_amax": (_i, [_p, _i64, _p, _p]),
+    "vd_amax_segments": (_i, [_p, _p, _i, _p, _p]),
+    "vd_amax_merge": (_i, [_p, _p, _p, _p]),
     "vd_add": (_i, [_p, _p, _p, _i64, _p]),
     "vd_fill": (_i, [_p, _f, _i64, _p]),
     "vd_upsample2x_concat": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -101,7 +109,7 @@ SIGNATURES = {
     "vd_nms_topk": (_i, [C.POINTER(HeadDesc), _p, _p, C.c_int32, _p, _f, _i, _i, _p, _p, _p, _p, _p, _i64, _p]),
     "vd_yolo_loss_ws_bytes": (_i64, [C.POINTER(HeadDesc)]),
     "vd_yolo_loss_fwd_bwd": (_i, [C.POINTER(HeadDesc), _p, _i, _p, _p, _p, _p, _p, _f, _i, _p,
-                                  C.POINTER(_fp * 3), _p, _p, _i64, _p]),
+                                  C.POINTER(_fp * 3), _p, C.POINTER(_fp * 3), _p, _i64, _p]),
     "vd_sgd_momentum": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _p]),
 }
 

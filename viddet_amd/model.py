@@ -94,7 +94,7 @@ class Program:
                 e1.record()
                 if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
                     meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT),
-                                bf16=bool(args[0]._obj.flags & L.MATH_BF16))
+                                bf16=bool(args[0]._obj.flags & L.MATH_BF16), f16x2=bool(args[0]._obj.flags & L.MATH_F16X2))
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
@@ -112,19 +112,23 @@ def fp32_math():
     plan-time autotuner times both per launch record and keeps the faster."""
     import os
     m = _MATH_OVERRIDE[0] or os.environ.get("VD_FP32_MATH", "auto")
-    if m not in ("native", "split", "auto", "bf16"):
-        raise ValueError("VD_FP32_MATH must be native|split|auto|bf16, got %r" % m)
+    if m not in _MATH_MODES:
+        raise ValueError("VD_FP32_MATH must be one of %s, got %r" % ("|".join(_MATH_MODES), m))
     return m
 
 
 _MATH_OVERRIDE = [None]
+# 'split2' = two-way fp16 operand split with per-tensor power-of-two scales (VD_MATH_F16X2: three MFMAs per product block
+# instead of six, fp32-accurate); 'auto' times native, split and split2 per launch record
+_MATH_MODES = ("native", "split", "split2", "auto", "bf16")
+_ALL_MATH = L.MATH_SPLIT | L.MATH_BF16 | L.MATH_F16X2
 
 
 def set_conv_math(mode):
     """Process-wide product arithmetic of the fp32-tensor convolutions for programs built from now on: None (the
     VD_FP32_MATH environment, default 'auto'), 'native', 'split', 'auto', or 'bf16' = products on bf16-rounded
     operands with fp32 accumulation (VD_MATH_BF16; the mixed-precision training arithmetic, bf16-accurate)."""
-    assert mode in (None, "native", "split", "auto", "bf16")
+    assert mode is None or mode in _MATH_MODES
     _MATH_OVERRIDE[0] = mode
 
 
@@ -138,8 +142,15 @@ def _tile_candidates(d, math):
             cands += [(0, 6), (0, 8)]
         else:
             cands += [(0, t) for t in (1, 2, 3, 4, 5)]
-    if math in ("split", "auto", "bf16"):
-        fl = L.MATH_BF16 if math == "bf16" else L.MATH_SPLIT
+    fls = []
+    if math in ("split", "auto"):
+        fls.append(L.MATH_SPLIT)
+    if math in ("split2", "auto"):
+        # the fp16 split needs the max-abs slots of both operands and has no in-load transform
+        fls.append(L.MATH_F16X2 if (d.amax_in and d.amax_w and not d.in_scale) else L.MATH_SPLIT)
+    if math == "bf16":
+        fls.append(L.MATH_BF16)
+    for fl in dict.fromkeys(fls):
         if d.Co <= 32:           # 256 x 32 tiles (9: 32x32x16 MFMA, 10: 16x16x32)
             cands += [(fl, t) for t in (9, 10)]
         elif d.Co <= 64:         # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
@@ -155,14 +166,15 @@ def autotune_desc(d, reps=3):
     the kernel's heuristic tile.  Tuning launches only rewrite buffers every real run rewrites first."""
     import os
     math = fp32_math()
-    base = d.flags & ~(L.MATH_SPLIT | L.MATH_BF16)
+    base = d.flags & ~_ALL_MATH
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
-        d.flags = base | (L.MATH_SPLIT if math == "split" else (L.MATH_BF16 if math == "bf16" else 0))
+        f16 = L.MATH_F16X2 if (d.amax_in and d.amax_w and not d.in_scale) else L.MATH_SPLIT
+        d.flags = base | {"split": L.MATH_SPLIT, "split2": f16, "bf16": L.MATH_BF16}.get(math, 0)
         return
     lib = L.load()
     s = L.stream_ptr()
     key = (math, d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, base, bool(d.in_scale),
-           bool(d.stats_part))
+           bool(d.stats_part), bool(d.amax_in and d.amax_w), bool(d.amax_out))
     if key in _TUNE_CACHE:
         fl, d.tile = _TUNE_CACHE[key]
         d.flags = base | fl
@@ -195,7 +207,7 @@ def autotune_desc(d, reps=3):
 
 
 def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
-    """Product arithmetic of one weight-gradient launch record (fp32 MFMA vs split operands), timed in place."""
+    """Product arithmetic of one weight-gradient launch record (fp32 MFMA vs the split forms), timed in place."""
     import os
     math = fp32_math()
     d.flags = 0
@@ -204,15 +216,16 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     if math == "bf16":
         d.flags = L.MATH_BF16
         return
-    if math == "split" or os.environ.get("VD_AUTOTUNE", "1") == "0":
-        d.flags = L.MATH_SPLIT
+    f16 = L.MATH_F16X2 if (d.amax_in and d.amax_dout and not d.in_scale) else L.MATH_SPLIT
+    if math in ("split", "split2") or os.environ.get("VD_AUTOTUNE", "1") == "0":
+        d.flags = f16 if math in ("split2", "auto") else L.MATH_SPLIT
         return
-    key = ('wgrad', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.Kfr, bool(d.in_scale))
+    key = ('wgrad', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.Kfr, bool(d.in_scale), f16)
     if key not in _TUNE_CACHE:
         lib = L.load()
         s = L.stream_ptr()
         best, best_t = 0, None
-        for fl in (0, L.MATH_SPLIT):
+        for fl in dict.fromkeys((0, L.MATH_SPLIT, f16)):
             d.flags = fl
             L.check(lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s), 'vd_conv_wgrad/tune')
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -588,6 +601,13 @@ class YOLOV3(object):
                 n.stat_off = soff
                 soff += 2 * round_up(n.cout, 64)
         self.running = torch.zeros(max(soff, 1), device=dev)
+        # max-abs of every conv weight tensor (operand scale of the VD_MATH_F16X2 arithmetic): one slot set per conv,
+        # refreshed by ONE launch whenever the weights moved (_refresh_wamax)
+        self._wamax = torch.zeros(len(self.conv_nodes) * L.AMAX_FLOATS, device=dev)
+        self._wamax_seg = torch.tensor([[n.w_off, n.w_numel] for n in self.conv_nodes], dtype=torch.int64, device=dev)
+        for i, n in enumerate(self.conv_nodes):
+            n.wamax = self._wamax[i * L.AMAX_FLOATS:(i + 1) * L.AMAX_FLOATS]
+        self._wamax_dirty = True
         # per-node derived buffers: folded scale/shift (eval) and batch scale/shift/mean/invstd (train)
         self.aux = torch.zeros(max(1, sum(6 * round_up(n.cout, 64) for n in self.conv_nodes if n.bn)), device=dev)
         self.sums = torch.zeros(max(1, sum(4 * round_up(n.cout, 64) for n in self.conv_nodes)), dtype=torch.float64,
@@ -769,6 +789,13 @@ class YOLOV3(object):
         self._fold_dirty = True
         self._dgrad_dirty = True
         self._bf16_fresh = False
+        self._wamax_dirty = True
+
+    def _refresh_wamax(self):
+        if self._wamax_dirty:
+            L.check(L.load().vd_amax_segments(self.weights.data_ptr(), self._wamax_seg.data_ptr(), len(self.conv_nodes),
+                                              self._wamax.data_ptr(), L.stream_ptr()), 'vd_amax_segments')
+            self._wamax_dirty = False
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, key, B, H, W, train):
@@ -785,6 +812,12 @@ class YOLOV3(object):
         if self.noback:
             for nm, c_, d_ in ROUTE_TENSORS:                                   # NCHW staging of the three inputs
                 bufs['in:' + nm] = torch.empty(B, c_, H // d_, W // d_, device=dev)
+        # max-abs slots (operand scales of the fp16-split arithmetic): one set per activation tensor, and in training
+        # per conv node for the gradient dz it consumes; zeroed by the first record of every forward program
+        names = [nm for nm in self.tensors if nm != 'in'] + (['dz:' + n.name for n in self.conv_nodes] if train else [])
+        bufs['amax'] = torch.zeros(len(names) * L.AMAX_FLOATS, device=dev)
+        for i, nm in enumerate(names):
+            bufs['amax:' + nm] = bufs['amax'][i * L.AMAX_FLOATS:(i + 1) * L.AMAX_FLOATS]
         if train:
             for n in self.nodes:
                 if isinstance(n, PoolNode) and n.type == 0:
@@ -808,7 +841,7 @@ class YOLOV3(object):
         return [H // 32, H // 16, H // 8]
 
     # ------------------------------------------------------------------ program builders
-    def _conv_desc(self, n, bufs, B, H, W, out, *, scale=None, shift=None, residual=None, leaky=False):
+    def _conv_desc(self, n, bufs, B, H, W, out, *, scale=None, shift=None, residual=None, leaky=False, amax_out=False):
         d = ConvDesc()
         x = bufs[n.src]
         Hi, Wi = H // n.div_in, W // n.div_in
@@ -832,14 +865,22 @@ class YOLOV3(object):
             flags |= EPI_RESIDUAL
             d.residual = residual.data_ptr()
         d.flags, d.slope = flags, LEAKY_SLOPE
+        d.amax_in, d.amax_w = bufs['amax:' + n.src].data_ptr(), n.wamax.data_ptr()
+        if amax_out:                                   # inference: the epilogue publishes the max-abs of what it writes
+            d.amax_out = bufs['amax:' + n.dst].data_ptr()
         return d
+
+    def _add_amax_reset(self, prog, bufs):
+        prog.add('vd_fill', bufs['amax'].data_ptr(), 0.0, bufs['amax'].numel())
 
     def _add_input_stage(self, prog, bufs, B, H, W):
         """Layout change of the network inputs: none for the frame batch (the stem kernel reads NCHW directly); the
         three cached feature maps of the no-backbone variant go NCHW -> NHWC."""
+        self._add_amax_reset(prog, bufs)
         if self.noback:
             for nm, c_, d_ in ROUTE_TENSORS:
                 prog.add('vd_nchw_to_nhwc', bufs['in:' + nm].data_ptr(), bufs[nm].data_ptr(), B, c_, H // d_, W // d_)
+                prog.add('vd_amax', bufs[nm].data_ptr(), bufs[nm].numel(), bufs['amax:' + nm].data_ptr())
 
     def _add_stem(self, prog, n, bufs, B, H, W, out, *, scale=None, shift=None, leaky=False, bf16=False, stats=None):
         """vd_stem_conv: the 3 -> 32 stem straight from the NCHW batch (vd_stem.hip)."""
@@ -859,11 +900,13 @@ class YOLOV3(object):
         bufs = self._buffers('infer', B, H, W, False)
         prog = Program()
         self._add_input_stage(prog, bufs, B, H, W)
+        am = lambda t: bufs['amax:' + t].data_ptr()
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
                 prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B * n.fr,
                          o.shape[1], o.shape[2], n.cu, n.cr)
+                prog.add('vd_amax_merge', am(n.up), am(n.route), am(n.dst))       # a concatenation: max of the two
                 continue
             if isinstance(n, PoolNode):
                 o, xs = bufs[n.dst], bufs[n.src]
@@ -871,16 +914,18 @@ class YOLOV3(object):
                     prog.add('vd_temporal_cat', xs.data_ptr(), o.data_ptr(), B, n.K, xs.shape[1] * xs.shape[2], xs.shape[3], 0)
                 else:
                     prog.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
+                prog.add('vd_amax_merge', am(n.src), None, am(n.dst))             # max / mean / stacking: bounded by the source's
                 continue
             if n.stem:
                 self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True)
+                prog.add('vd_amax', bufs[n.dst].data_ptr(), bufs[n.dst].numel(), am(n.dst))
                 continue
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
             else:
                 res = bufs[n.residual] if n.residual else None
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
-                                    leaky=True)
+                                    leaky=True, amax_out=True)
             prog.hold(d)
             prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
         grids = self._grid(H, W)
@@ -1080,6 +1125,7 @@ class YOLOV3(object):
             prog, bufs, o = self._programs[key]
             self._refresh_fold()
         self._stage_inputs(bufs, x)
+        self._refresh_wamax()
         if self.use_graphs:
             g = self._graph_cache.get(key)
             if g is None:
@@ -1114,16 +1160,18 @@ class YOLOV3(object):
             for n in self.nodes[:last + 1]:
                 if n.stem:
                     self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True)
+                    prog.add('vd_amax', bufs[n.dst].data_ptr(), bufs[n.dst].numel(), bufs['amax:' + n.dst].data_ptr())
                     continue
                 res = bufs[n.residual] if n.residual else None
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, residual=res,
-                                    leaky=True)
+                                    leaky=True, amax_out=True)
                 prog.hold(d)
                 prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
             autotune_program(prog)
             self._programs[key] = (prog, bufs)
         prog, bufs = self._programs[key]
         self._refresh_fold()
+        self._refresh_wamax()
         self._stage_inputs(bufs, x)
         prog.run()
         return tuple(bufs[nm].permute(0, 3, 1, 2).contiguous() for nm, _, _ in ROUTE_TENSORS)
@@ -1178,11 +1226,13 @@ class YOLOV3(object):
             segments.append(fn)
             return Program()
 
+        amx = lambda t: bufs['amax:' + t].data_ptr()
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
                 seg.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B * n.fr,
                         o.shape[1], o.shape[2], n.cu, n.cr)
+                seg.add('vd_amax_merge', amx(n.up), amx(n.route), amx(n.dst))
                 continue
             if isinstance(n, PoolNode):
                 o, xs = bufs[n.dst], bufs[n.src]
@@ -1191,6 +1241,7 @@ class YOLOV3(object):
                 else:
                     am = bufs['am:' + n.dst].data_ptr() if n.type == 0 else None
                     seg.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), am, B, n.K, o[0].numel(), n.type)
+                seg.add('vd_amax_merge', amx(n.src), None, amx(n.dst))
                 continue
             Ho, Wo = H // n.div_out, W // n.div_out
             M = B * n.fr * Ho * Wo
@@ -1243,7 +1294,7 @@ class YOLOV3(object):
                 seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, *fin)
             res = bufs[n.residual].data_ptr() if n.residual else None
             seg.add('vd_bn_apply_leaky', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
-                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE)
+                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE, amx(n.dst))
         # loss (targets are late-bound)
         grids = self._grid(H, W)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
@@ -1251,11 +1302,13 @@ class YOLOV3(object):
         slots = dict(gt=Slot(), M=Slot(), obj=Slot(), ctr=Slot(), scl=Slot(), wgt=Slot(), cls=Slot(), smooth=Slot())
         losses = torch.zeros(B * self._head_frames, 4, device=dev)
         dh = (C.c_void_p * 3)(*[bufs['d:' + h].data_ptr() for h in self.head_names])
+        head_node = {m.dst: m for m in self.conv_nodes if m.head}
+        dha = (C.c_void_p * 3)(*[amx('dz:' + head_node[h].name) for h in self.head_names])   # max-abs of the three dhead
         lws = torch.empty(max(16, ops.yolo_loss_ws_bytes(hd)), dtype=torch.uint8, device=dev)
-        seg.hold(hd, dh, lws)
+        seg.hold(hd, dh, dha, lws)
         seg.add('vd_yolo_loss_fwd_bwd', C.byref(hd), slots['gt'], slots['M'], slots['obj'], slots['ctr'], slots['scl'],
                 slots['wgt'], slots['cls'], float(self._ignore_iou_thresh), slots['smooth'], losses.data_ptr(),
-                C.byref(dh), None, lws.data_ptr(), lws.numel())
+                C.byref(dh), None, C.byref(dha), lws.data_ptr(), lws.numel())
         fwd.append(seg)
 
         # ---- backward
@@ -1320,7 +1373,7 @@ class YOLOV3(object):
                 src = alias.pop(name)
                 seg.add('vd_bn_apply_leaky', src.data_ptr(), self._ones(src.shape[-1]).data_ptr(),
                         self._zeros(src.shape[-1]).data_ptr(), None, bufs['d:' + name].data_ptr(),
-                        src.numel() // src.shape[-1], src.shape[-1], 1.0)
+                        src.numel() // src.shape[-1], src.shape[-1], 1.0, None)
 
         def grad_into(name, numel, can_alias=False):
             """Return (dst_ptr, accumulate?) for a producer of d:name."""
@@ -1412,7 +1465,7 @@ class YOLOV3(object):
                     seg.add_py(ev_wait(dz_free[slot], False))       # the wgrad that read this scratch has finished
                 seg.add('vd_bn_bwd_apply', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
-                        dz.data_ptr())
+                        dz.data_ptr(), amx('dz:' + n.name))
             # weight gradient straight into the gradient arena (same fwd-packed layout as the weights)
             if n.stem and w_train:
                 # both operands straight from global memory: the NCHW batch and dz (vd_stem.hip)
@@ -1444,6 +1497,7 @@ class YOLOV3(object):
                 wd_.in_stride = n.stride
                 ops._set_taps(wd_, n.taps())
                 wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
+                wd_.amax_in, wd_.amax_dout = amx(n.src), amx('dz:' + n.name)
                 autotune_wgrad(wd_, ws.data_ptr(), ws_bytes)
                 seg.hold(wd_)
                 if side is not None:
@@ -1491,6 +1545,7 @@ class YOLOV3(object):
                 d.out_stride, d.out_oy, d.out_ox = n.stride, plan['py'], plan['px']
                 d.ldo = d.ldr = n.cin
                 d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
+                d.amax_in, d.amax_w = amx('dz:' + n.name), n.wamax.data_ptr()
                 if acc:
                     d.residual = res_src.data_ptr()
                 seg.hold(d, wpk)
@@ -1594,6 +1649,7 @@ class YOLOV3(object):
         s['wgt'].value, s['cls'].value = wgt.data_ptr(), cls.data_ptr()
         s['smooth'].value = 1 if self._label_smooth else 0
         self._stage_inputs(tp['bufs'], x)
+        self._refresh_wamax()
         self._refresh_dgrad(tp, overlap=True)
         self._run_segments(tp['fwd'])
         self._fold_dirty = True            # running stats moved

@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, MATH_BF16, check, ptr
+from .lib import (ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, MATH_BF16, MATH_F16X2,
+                  AMAX_FLOATS, check, ptr)
 
 
 def round_up(v, m):
@@ -75,7 +76,11 @@ def _set_taps(d, taps):
 # --------------------------------------------------------------------------------------------
 def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo,
                out_stride=1, out_oy=0, out_ox=0, scale=None, shift=None, residual=None, ldr=0,
-               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0, split=False):
+               leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0, split=False,
+               amax_in=None, amax_w=None, amax_out=None):
+    """split: False = fp32 MFMA; True / 'split' = exact 3-plane bf16 split; 'bf16' = one plane (bf16-rounded operands);
+    'f16x2' = two fp16 planes with per-tensor scales - the max-abs slots of x and wp (amax_in / amax_w, see amax())
+    are computed here when not given."""
     d = ConvDesc()
     d.tile = tile
     d.in_, d.wp, d.out = ptr(x), ptr(wp), ptr(out)
@@ -94,15 +99,22 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
         flags |= EPI_LEAKY
     if residual is not None:
         flags |= EPI_RESIDUAL
-    if split:                       # True / 'split': exact 3-plane split; 'bf16': one plane (bf16-rounded operands)
+    if split == 'f16x2':
+        flags |= MATH_F16X2
+        amax_in = amax(x) if amax_in is None else amax_in
+        amax_w = amax(wp) if amax_w is None else amax_w
+        d.amax_in, d.amax_w = ptr(amax_in), ptr(amax_w)
+    elif split:
         flags |= MATH_BF16 if split == 'bf16' else MATH_SPLIT
+    d.amax_out = ptr(amax_out)
     d.flags, d.slope = flags, slope
     d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
     check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm")
 
 
 def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
-             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0, split=False):
+             leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0, split=False, amax_in=None, amax_w=None,
+             amax_out=None):
     """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo]."""
     N, Hi, Wi, Ci = x.shape
     Ho = (Hi + 2 * pad - k) // stride + 1
@@ -110,11 +122,13 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     ldo = Co if ldo is None else ldo
     conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
                taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
-               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile, split=split)
+               residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile, split=split,
+               amax_in=amax_in, amax_w=amax_w, amax_out=amax_out)
     return Ho, Wo
 
 
-def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0, split=False):
+def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0, split=False, amax_in=None,
+               amax_dout=None):
     """dwp [Co][T*Ci] (fwd-packed layout) = wgrad(x [N,Hi,Wi,Ci], dout [N,Ho,Wo,Co])."""
     N, Hi, Wi, Ci = x.shape
     _, Ho, Wo, ldd = dout.shape
@@ -125,7 +139,13 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
-    d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
+    if split == 'f16x2':
+        d.flags = MATH_F16X2
+        amax_in = amax(x) if amax_in is None else amax_in
+        amax_dout = amax(dout) if amax_dout is None else amax_dout
+        d.amax_in, d.amax_dout = ptr(amax_in), ptr(amax_dout)
+    else:
+        d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
     if need > ws.numel() * ws.element_size():
@@ -140,7 +160,7 @@ def wgrad_ws_bytes(N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, kd=1, pad_d=0):
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = 1, 0
     need = 0
-    for fl in (0, MATH_SPLIT):          # the two product arithmetics pick different split counts
+    for fl in (0, MATH_SPLIT):          # the product arithmetics pick different split counts (every split form: the same)
         d.flags = fl
         need = max(need, _lib().vd_conv_wgrad_ws_bytes(C.byref(d)))
     return need
@@ -216,9 +236,9 @@ def bn_fold_eval(gamma, beta, rmean, rvar, eps, scale, shift):
                                  ptr(shift), _s()), "vd_bn_fold_eval")
 
 
-def bn_apply_leaky(x, scale, shift, residual, y, M, C_, slope=0.1):
-    check(_lib().vd_bn_apply_leaky(ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(y), M, C_, slope, _s()),
-          "vd_bn_apply_leaky")
+def bn_apply_leaky(x, scale, shift, residual, y, M, C_, slope=0.1, amax_out=None):
+    check(_lib().vd_bn_apply_leaky(ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(y), M, C_, slope, ptr(amax_out),
+                                   _s()), "vd_bn_apply_leaky")
 
 
 def bn_bwd_reduce(x, dy, scale, shift, smean, sinv, M, C_, sums2, ws, slope=0.1):
@@ -230,14 +250,26 @@ def bn_param_grads(sums2, C_, dgamma, dbeta):
     check(_lib().vd_bn_param_grads(ptr(sums2), C_, ptr(dgamma), ptr(dbeta), _s()), "vd_bn_param_grads")
 
 
-def bn_bwd_apply(x, dy, scale, shift, smean, sinv, sums2, count, M, C_, dx, slope=0.1):
+def bn_bwd_apply(x, dy, scale, shift, smean, sinv, sums2, count, M, C_, dx, slope=0.1, amax_out=None):
     check(_lib().vd_bn_bwd_apply(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), ptr(sums2),
-                                 float(count), M, C_, slope, ptr(dx), _s()), "vd_bn_bwd_apply")
+                                 float(count), M, C_, slope, ptr(dx), ptr(amax_out), _s()), "vd_bn_bwd_apply")
 
 
 # --------------------------------------------------------------------------------------------
 # pointwise
 # --------------------------------------------------------------------------------------------
+def amax(x, out=None):
+    """Max-abs slots (AMAX_FLOATS floats) of a tensor: the operand-scale input of the VD_MATH_F16X2 arithmetic."""
+    out = torch.empty(AMAX_FLOATS, device=x.device) if out is None else out
+    check(_lib().vd_amax(ptr(x), x.numel(), ptr(out), _s()), "vd_amax")
+    return out
+
+
+def amax_value(slots):
+    """The tensor's max-abs as a Python float (tests / diagnostics; synchronises)."""
+    return float(slots.view(-1)[::L.AMAX_STRIDE][:L.AMAX_SLOTS].max())
+
+
 def add(a, b, out):
     check(_lib().vd_add(ptr(a), ptr(b), ptr(out), out.numel(), _s()), "vd_add")
 
@@ -307,11 +339,12 @@ def nms_topk(h, cand_score, cand_row, cap, counts, nms_thresh, topk, post_nms, i
 
 
 def yolo_loss_fwd_bwd(h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh, label_smooth, losses,
-                      dheads, box_out, ws):
+                      dheads, box_out, ws, dhead_amax=None):
     arr = (C.c_void_p * 3)(*[t.data_ptr() for t in dheads])
+    am = None if dhead_amax is None else C.byref((C.c_void_p * 3)(*[t.data_ptr() for t in dhead_amax]))
     check(_lib().vd_yolo_loss_fwd_bwd(C.byref(h), ptr(gt), M, ptr(obj_t), ptr(center_t), ptr(scale_t), ptr(weight_t),
                                       ptr(class_t), ignore_thresh, 1 if label_smooth else 0, ptr(losses),
-                                      C.byref(arr), ptr(box_out), ptr(ws), ws.numel() * ws.element_size(), _s()),
+                                      C.byref(arr), ptr(box_out), am, ptr(ws), ws.numel() * ws.element_size(), _s()),
           "vd_yolo_loss_fwd_bwd")
 
 
