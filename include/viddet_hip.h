@@ -56,6 +56,9 @@ extern "C" {
  * VD_AMAX_STRIDE floats apart, written by the producing kernels (atomic max; the caller zeroes them before the producer
  * runs) or by vd_amax / vd_amax_segments.  Measured against fp64 the error is not above the fp32 MFMA's. */
 #define VD_MATH_F16X2    64
+/* with VD_MATH_F16X2: keep the generic K loop where the library would stage the activation operand as a pixel halo tile
+ * (3x3 stride-1 convs and their data gradients; vd_conv.hip, HALO) - for A/B timing by the host autotuner */
+#define VD_MATH_NOHALO   128
 #define VD_AMAX_SLOTS    32
 #define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
 #define VD_AMAX_FLOATS   (VD_AMAX_SLOTS * VD_AMAX_STRIDE)   /* floats per tensor */

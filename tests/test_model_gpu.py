@@ -270,7 +270,9 @@ def test_fp16_split_arithmetic_matches_oracle(cfg):
         for s_, hname in enumerate(net.head_names):
             assert maxdiff(bufs[hname].cpu().numpy()[..., :3 * (5 + c)], np.moveaxis(heads_r[s_], 1, -1)) < 1e-3, s_
         perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
-        assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 5e-3
+        assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3
+        # boxes: 5e-3 px, or 2e-5 of the coordinate for the exp()-blown boxes of this random-init fixture (+-1700 px)
+        assert np.all(np.abs(take_ranks(bx, perm) - bx_r) <= 5e-3 + 2e-5 * np.abs(bx_r))
         used = [bool(a[0]._obj.flags & L.MATH_F16X2) for (fn_, _, a) in net._programs[('infer', b, size, size)][0].recs
                 if fn_ == 'vd_conv_igemm']
         assert sum(used) >= 70, sum(used)

@@ -19,10 +19,13 @@ TOL = 2e-4
 SHAPES = [  # n, ci, h, w, co, k, stride, pad
     (2, 64, 8, 8, 128, 3, 1, 1), (6, 128, 8, 8, 256, 3, 1, 1), (3, 32, 13, 11, 96, 1, 1, 0),
     (2, 64, 17, 15, 160, 3, 2, 1), (5, 96, 21, 19, 320, 3, 1, 1), (1, 64, 19, 19, 255, 1, 1, 0),
+    (7, 64, 13, 13, 128, 3, 1, 1),        # several 13x13 images per 256-pixel tile: halo rows cross image borders
+    (1, 32, 104, 104, 64, 3, 1, 1),       # the widest map the halo loop takes (halo = 466 rows, one 32-channel chunk)
+    (2, 160, 52, 52, 96, 3, 1, 1),        # five chunks: the stream wraps the halo buffers
 ]
 
 
-@pytest.mark.parametrize("mode", [True, "f16x2"])
+@pytest.mark.parametrize("mode", [True, "f16x2", "f16x2nh"])      # f16x2: halo-staged loop on the 3x3 stride-1 shapes
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])      # 5..8: the same tiles on the 16x16x32 MFMA shape
 @pytest.mark.parametrize("shape", SHAPES)
 def test_split_fwd_every_tile(tile, shape, mode):
@@ -68,8 +71,9 @@ def test_split_fwd_32_column_tiles(tile, shape, mode):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 12, 12, 128, 3, 1, 1), (2, 32, 20, 20, 64, 3, 2, 1), (1, 64, 15, 17, 128, 3, 2, 1),
-                                  (3, 256, 13, 13, 128, 1, 1, 0), (2, 96, 9, 9, 75, 1, 1, 0)])
-@pytest.mark.parametrize("mode", [True, "f16x2"])
+                                  (3, 256, 13, 13, 128, 1, 1, 0), (2, 96, 9, 9, 75, 1, 1, 0), (3, 64, 26, 26, 128, 3, 1, 1),
+                                  (1, 128, 104, 104, 64, 3, 1, 1)])
+@pytest.mark.parametrize("mode", [True, "f16x2", "f16x2nh"])
 def test_split_dgrad(case, mode):
     from viddet_amd import ops
     n, ci, h, w, co, k, s, p = case
@@ -249,8 +253,10 @@ def test_amax_slots_from_every_producer():
     assert ops.amax_value(slot) == float(dx.abs().max())
 
 
-def test_split_fused_bn_statistics():
-    """Fused per-M-tile BatchNorm partial sums out of the split-math epilogue (256- and 128-row tiles)."""
+@pytest.mark.parametrize("math", ["split", "f16x2", "f16x2nh"])
+def test_split_fused_bn_statistics(math):
+    """Fused per-M-tile BatchNorm partial sums out of the split-math epilogue (256- and 128-row tiles; generic and
+    halo-staged K loops)."""
     from viddet_amd import ops
     from viddet_amd import lib as L
     import ctypes as C
@@ -258,16 +264,19 @@ def test_split_fused_bn_statistics():
     rng, x, wt = _mk(n, ci, h, w, co, k, 123)
     ref = R.conv2d(x, wt, 1, 1)
     M = n * h * w
+    fl = {"split": L.MATH_SPLIT, "f16x2": L.MATH_F16X2, "f16x2nh": L.MATH_F16X2 | L.MATH_NOHALO}[math]
     for tile in (1, 2, 3, 4, 5, 6, 7, 8):
         d = L.ConvDesc()
         xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+        ax, aw = ops.amax(xd), ops.amax(wp)
+        d.amax_in, d.amax_w = ax.data_ptr(), aw.data_ptr()
         out = torch.empty(n, h, w, co, device="cuda")
         part = torch.zeros(64, 2 * co, device="cuda")
         d.in_, d.wp, d.out = xd.data_ptr(), wp.data_ptr(), out.data_ptr()
         d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, h, w, ci, h, w, 1
         ops._set_taps(d, ops.fwd_taps(k, 1))
         d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo = 1, h, w, co, 1, co
-        d.flags, d.tile, d.stats_part = L.MATH_SPLIT, tile, part.data_ptr()
+        d.flags, d.tile, d.stats_part = fl, tile, part.data_ptr()
         lib = L.load()
         L.check(lib.vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
         mt = lib.vd_conv_igemm_mtiles(C.byref(d))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time ONE forward conv shape (events, median of several launches) — used with VD_IGEMM_PROBE timing probes.
-usage: conv_probe.py cin cout k stride hin [tile] [split] [batch]"""
+usage: conv_probe.py cin cout k stride hin [tile] [split: 0 | 1 | f16x2 | f16x2nh | bf16] [batch]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from viddet_amd import ops
 
 cin, cout, k, s, hin = [int(v) for v in sys.argv[1:6]]
 tile = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-split = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+split = (sys.argv[7] if sys.argv[7] in ('f16x2', 'f16x2nh', 'bf16') else bool(int(sys.argv[7]))) if len(sys.argv) > 7 else False
 B = int(sys.argv[8]) if len(sys.argv) > 8 else 64
 pad = k // 2
 ho = (hin + 2 * pad - k) // s + 1
@@ -31,5 +31,5 @@ for i in range(12):
     ts.append(e0.elapsed_time(e1))
 ts = sorted(ts[2:])
 t = ts[len(ts) // 2]
-print("probe=%s tile=%d split=%d  %.3f ms  %.1f TFLOP/s" % (os.environ.get("VD_IGEMM_PROBE", "0"), tile, split, t,
+print("lib=%s tile=%d split=%s  %.3f ms  %.1f TFLOP/s" % (os.path.basename(os.environ.get("VD_LIB", "default")), tile, split, t,
                                                         2.0 * cin * cout * k * k * ho * ho * B / t / 1e9))

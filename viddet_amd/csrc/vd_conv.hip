@@ -38,6 +38,12 @@ namespace {
 #ifndef VD_PD
 #define VD_PD 3
 #endif
+#ifndef VD_BNT
+#define VD_BNT 0
+#endif
+#ifndef VD_KROT
+#define VD_KROT 0
+#endif
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
@@ -177,10 +183,17 @@ struct RowInfo {
 // (second launch bound: the 8-wave fp32-MFMA tiles run two workgroups per CU = 4 waves per SIMD = 128 VGPRs)
 // NPL: bf16 planes per operand in the split arithmetic - 3 = exact split, 6 partial products (fp32-accurate);
 // 1 = only the leading piece, ONE bf16 MFMA per product block (VD_MATH_BF16: bf16-rounded operands, fp32 accumulate).
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3>
+// HALO (NPL == 2, 3x3 stride-1 'same' geometry, forward and data gradient): the activation operand is staged ONCE per
+// 32-channel chunk as a pixel halo tile - the BM output pixels of the tile plus W+1 pixels either side, split into fp16
+// planes - and the nine taps read it at shifted rows, instead of gathering and splitting the same pixels nine times.
+// Measured on the generic loop (timing probes, tools/conv_probe.py): the activation gather's vector-memory instructions
+// cost 30 % of a 3x3 launch wherever they hit (L1, L2 or HBM) - the CU's load path, not the memory system, is the limit -
+// so the fix is fewer bytes INTO the CU: (BM + 2W + 2) / (9 BM) of them.
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3, bool HALO = false>
 __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     static_assert(NPL == 3 || ((NPL == 1 || NPL == 2) && SP), "planes");
     static_assert(NPL != 2 || !XF, "the fp16 split needs the max-abs of the operand it splits: no in-load transform");
+    static_assert(!HALO || (NPL == 2 && WM * WN == 8 && WN * TN * 32 >= 64), "the halo loop exists for the 8-wave fp16-split tiles");
     constexpr int SP_ROWB = NPL * 64;          // LDS row of the split arithmetic: NPL planes of 32 bf16 (fp16 for NPL == 2)
     constexpr int NTERM = Terms<NPL>::N;
     static_assert(!M16 || SP, "the 16x16x32 shape exists for the bf16 operands of the split arithmetic");
@@ -280,7 +293,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     // register sets = K-steps of global-load latency cover (the 4-wave 128x128 tile has no VGPRs left for a third)
     constexpr int PD = (VD_PD > 2 && ((WM * WN == 4 && TM * TN == 4) || (M16 && TM * TN == 4))) ? 2 : VD_PD;
     f32x4 ra[PD][AP], rb[PD][BP];
-    int t_tap = 0, c0 = 0;   // k-step cursor of the NEXT tile to load
+    // k-step cursor of the NEXT tile to load.  VD_KROT: every M tile starts the channel-chunk loop at a different chunk (and
+    // wraps), so that at any moment the workgroups of the chip read different 128-B pieces of the 4*Ci-byte pixel records
+    // instead of all the same one (memory-channel balance); a tile's sum order is rotated, not its value set
+    int t_tap = 0, c0 = VD_KROT ? (int)((unsigned)tile_m % (unsigned)(p.Ci / BK)) * BK : 0;
 
     // tap part of the wave-uniform source offset: refreshed only when the tap changes (every Ci/32 K-steps), so the
     // scalar loads of dy/dx/dz and their s_waitcnt leave the per-step critical path
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         for (int i = 0; i < AP; ++i) {
             const bool ok = (ri[i].mask >> t_tap) & 1u;
             const int64_t o = ri[i].off + soff;
-            const int64_t sel = ok ? o : zd_in;
+            const int64_t sel = (ok && !(VD_PROBE & 8) && !((VD_PROBE & 32) && t_tap != 0)) ? o : zd_in;   // probe bit 3: every A request hits the zero page; bit 5: all but tap 0's
             f32x4 v = *reinterpret_cast<const f32x4*>(p.in + sel);
             if (XF) {
 #pragma unroll
@@ -319,8 +335,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int64_t o = boff[i] + koff;
-            const int64_t sel = boff[i] >= 0 ? o : zd_w;
+            const int64_t sel = (boff[i] >= 0 && !(VD_PROBE & 16)) ? o : zd_w;   // probe bit 4: same for the weights
+#if VD_BNT
+            rb[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.wp + sel));   // weights bypass the CU's L1
+#else
             rb[i] = *reinterpret_cast<const f32x4*>(p.wp + sel);
+#endif
         }
 #if VD_KORDER
         // taps innermost: the T taps of one 32-channel chunk touch (almost) the same pixels, shifted
@@ -328,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         if (t_tap >= p.T) {
             t_tap = 0;
             c0 += BK;
+            if (VD_KROT && c0 >= p.Ci) c0 = 0;
         }
         tap_soff = tap_off(t_tap);
 #else
@@ -506,13 +527,263 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 
     const int nks = p.T * (p.Ci / BK);
     STAMP(1);
+    if constexpr (HALO) {
+        // ---- LDS: two halo buffers [R + 2 rows][128 B] (row R = zeros for taps outside the image, row R + 1 = a sink for
+        // the stream's idle slots), then the ring of three weight stages [BN][128 B]
+        constexpr int HT = 9;                                  // taps (3x3), checked on the host
+        const int W = p.Wi;
+        const int R = BM + 2 * (W + 1);
+        const int ZROW = R, DROW = R + 1;
+        const int ABUF = (R + 2) * 128;
+        char* Ah = As3;
+        char* Bh = As3 + 2 * ABUF;
+        const int nchunk = p.Ci / BK;
+        const int64_t m0 = (int64_t)tile_m * BM;
+        const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;       // == M in this geometry
+        if (tid < 16) *reinterpret_cast<f32x4*>(Ah + (tid >> 3) * ABUF + ZROW * 128 + (tid & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- per MFMA operand row: halo row of the centre tap and the 9-bit mask of taps inside the image
+        constexpr int NRB = M16 ? 2 * TM : TM;                 // operand row blocks per wave (16 or 32 rows each)
+        constexpr int RBS = M16 ? 16 : 32;
+        int jbase[NRB];
+        unsigned amask[NRB];
+#pragma unroll
+        for (int b = 0; b < NRB; ++b) {
+            const int il = wm * TM * 32 + b * RBS + (lane & (RBS - 1));       // output pixel within the tile
+            const int64_t m = m0 + il;
+            const unsigned mu = m < M ? (unsigned)m : 0u;
+            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+            const int gx = (int)(mu - t * (unsigned)p.Wg);
+            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            unsigned mk = 0u;
+            for (int t2 = 0; t2 < HT; ++t2) {
+                const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2);
+                mk |= ((unsigned)(gy + dy) < (unsigned)p.Hi && (unsigned)(gx + dx) < (unsigned)p.Wi) ? (1u << t2) : 0u;
+            }
+            amask[b] = m < M ? mk : 0u;
+            jbase[b] = il + W + 1;
+        }
+        const int tap_ro = tap_dy * W + tap_dx;                // lane t: halo-row offset of tap t
+        // ---- halo stream: item (chunk c, slot s) = rows lrow + 64 s of chunk c's halo, one float4 per thread.  Everything
+        // that depends only on the thread is hoisted: the slot's validity (9 bits), the element offset of slot 0, the LDS
+        // byte offset of slot 0 and the swizzle key (64 s leaves the low four row bits alone; the sink row takes whatever
+        // slot the key gives it)
+        const int hcs = (tid & 7) >> 1, hhalf = (tid & 1) << 3;
+        unsigned hvalid = 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < HT; ++s2) {
+            const int j = lrow + 64 * s2;
+            const int64_t pin = m0 - (W + 1) + j;
+            hvalid |= (j < R && (uint64_t)pin < (uint64_t)Mtot) ? (1u << s2) : 0u;
+        }
+        const int64_t hoff0 = (m0 - (W + 1) + lrow) * (int64_t)p.Ci + lc4;      // element offset of (slot 0, chunk 0)
+        const int64_t hslot = 64ll * p.Ci;                                      // elements between slots
+        const int hkey = f16x2_key(lrow);
+        const int hl0 = lrow * 128 + hhalf + ((hcs ^ hkey) << 4);               // LDS byte offset of the h piece, slot 0
+        const int hl1 = lrow * 128 + hhalf + (((4 + hcs) ^ hkey) << 4);         // ... of the l piece
+        const int hsink = (DROW - lrow) * 128;                                  // hl0 + hsink lies in the sink row
+        auto hload = [&](int c, int s) -> f32x4 {
+            const bool ok = ((hvalid >> s) & 1u) && c < nchunk;
+            const int64_t sel = ok ? hoff0 + (int64_t)s * hslot + (int64_t)c * BK : zd_in;
+            return *reinterpret_cast<const f32x4*>(p.in + sel);
+        };
+        auto hstore = [&](const f32x4 v, int c, int s) {
+            const int ro_ = (c & 1) * ABUF + (((hvalid >> s) & 1u) ? s * 8192 : hsink);
+            uint2 h, l;
+            split2(v, scl_a, h, l);
+            *reinterpret_cast<uint2*>(Ah + ro_ + hl0) = h;
+            *reinterpret_cast<uint2*>(Ah + ro_ + hl1) = l;
+        };
+        // ---- weights: the generic loop's requests / stores, weight operand only
+        int bt = 0, bc0 = 0;
+        auto gloadB = [&](f32x4 (&rb)[BP]) {
+            const int64_t koff = (int64_t)bt * p.Ci + bc0;
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
+                rb[i] = *reinterpret_cast<const f32x4*>(p.wp + sel);
+            }
+            if (++bt >= HT) { bt = 0; bc0 += BK; }
+        };
+        auto lstoreB = [&](int buf, const f32x4 (&rb)[BP]) {
+            const int key = f16x2_key(lrow);
+            const int oh = ((hcs ^ key) << 4) + hhalf, ol = (((4 + hcs) ^ key) << 4) + hhalf;
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                uint2 h, l;
+                split2(rb[i], scl_b, h, l);
+                char* r = Bh + (buf * BN + lrow + RPP * i) * 128;
+                *reinterpret_cast<uint2*>(r + oh) = h;
+                *reinterpret_cast<uint2*>(r + ol) = l;
+            }
+        };
+        // byte offsets (within Ah) of the lane's operand rows for one (halo buffer, tap), slot key folded in; computed one
+        // K-step ahead so that a step opens with its LDS reads, not with their address arithmetic
+        const int lsel = M16 ? (lane >> 4) : (lane >> 5);
+        auto hrows = [&](int (&av)[NRB], int abuf, int tap) {
+            const int ro = __builtin_amdgcn_readlane(tap_ro, tap);
+#pragma unroll
+            for (int b = 0; b < NRB; ++b) {
+                const int j = ((amask[b] >> tap) & 1u) ? jbase[b] + ro : ZROW;
+                av[b] = abuf * ABUF + j * 128 + ((f16x2_key(j) ^ lsel) << 4);
+            }
+        };
+        // ---- MFMA operand fragments, software-pipelined: a K-step never opens with exposed LDS latency.  The measured
+        // ceiling of the [8 reads -> wait -> 12 MFMAs] x 2 step (a bare read + MFMA loop) was ~50 % of the matrix pipe: the
+        // two waves of a SIMD leave the barrier together and wait for their reads together.  Here the reads of half-step
+        // h + 1 are issued before the MFMAs of half-step h (for the second half of a step that is the NEXT K-step's first
+        // half: its weight tile sits in the third ring slot, stored a step ago and published by the last barrier).
+        const int swz = f16x2_key(lane & (RBS - 1));
+        auto fragsA = [&](v4i (&fa)[NRB][2], const int (&av)[NRB], int kc) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int b2 = 0; b2 < NRB; ++b2)
+                    fa[b2][q] = *reinterpret_cast<const v4i*>(Ah + (av[b2] ^ ((4 * q + (M16 ? 0 : 2 * kc)) << 4)));
+        };
+        // non-M16: the TN 32-column blocks of k-half kc; M16: ONE 16-column block nb (all 32 k)
+        auto fragsB = [&](v4i (&fb)[M16 ? 1 : TN][2], int slot, int sub) {
+            const char* b3 = Bh + (slot * BN + wn * TN * 32 + (lane & (RBS - 1))) * 128 + (M16 ? sub * 16 * 128 : 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ni = 0; ni < (M16 ? 1 : TN); ++ni)
+                    fb[ni][q] = *reinterpret_cast<const v4i*>(b3 + ni * 32 * 128 + (((4 * q + (M16 ? 0 : 2 * sub) + lsel) ^ swz) << 4));
+        };
+        auto mm32 = [&](const v4i (&fa)[NRB][2], const v4i (&fb)[M16 ? 1 : TN][2]) {
+#if VD_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = mfma32<2>(fa[mi][Terms<2>::QA[t]], fb[M16 ? 0 : ni][Terms<2>::QB[t]], acc[mi][ni]);
+#if VD_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        };
+        auto mm16 = [&](const v4i (&fa)[NRB][2], const v4i (&fb)[M16 ? 1 : TN][2], int nb) {
+#if VD_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int mb = 0; mb < 2 * TM; ++mb) {
+                f32x16& A_ = acc[mb >> 1][nb >> 1];
+                const int e0 = 4 * (2 * (mb & 1) + (nb & 1));
+                f32x4 c = {A_[e0], A_[e0 + 1], A_[e0 + 2], A_[e0 + 3]};
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    c = mfma16<2>(fa[M16 ? mb : 0][Terms<2>::QA[t]], fb[0][Terms<2>::QB[t]], c);
+                A_[e0] = c[0]; A_[e0 + 1] = c[1]; A_[e0 + 2] = c[2]; A_[e0 + 3] = c[3];
+            }
+#if VD_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        };
+        // ---- prologue: the whole halo of chunk 0, the first two weight tiles, and the heads of the request streams
+        {
+            f32x4 t9[HT];
+#pragma unroll
+            for (int s2 = 0; s2 < HT; ++s2) t9[s2] = hload(0, s2);
+#pragma unroll
+            for (int s2 = 0; s2 < HT; ++s2) hstore(t9[s2], 0, s2);
+        }
+        gloadB(rb[0]);
+        lstoreB(0, rb[0]);
+        gloadB(rb[0]);
+        lstoreB(1, rb[0]);
+        __syncthreads();
+        constexpr int HD = 3;                                  // halo items in flight (one request and one store per K-step)
+        f32x4 hv[HD];
+        int hc = 1, hs = 0;                                    // next item to request (chunk, slot)
+        int sc = 1, ss = 0;                                    // next item to store
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            hv[d] = hload(hc, hs);
+            if (++hs >= HT) { hs = 0; ++hc; }
+        }
+        // weight tile t travels: requested at step t - PD - 1 (set t % PD), stored at step t - 2 (ring slot t % 3), read from
+        // step t - 1 on
+#pragma unroll
+        for (int d = 2; d <= PD; ++d)
+            if (d < nks) gloadB(rb[d % PD]);
+        constexpr int UNH = 6;                                 // = lcm(3 ring slots, PD in {2, 3}, HD)
+        static_assert(UNH % PD == 0 && UNH % HD == 0 && UNH % 3 == 0, "unroll vs register sets / ring");
+        int cc = 0, ct = 0;                                    // chunk / tap of the step being multiplied
+        int avc[NRB];
+        hrows(avc, 0, 0);
+        v4i FA0[NRB][2], FA1[NRB][2], FB0[M16 ? 1 : TN][2], FB1[M16 ? 1 : TN][2];
+        fragsA(FA0, avc, 0);
+        fragsB(FB0, 0, 0);
+        auto hstep = [&](int u, bool has_next, bool do_req, bool do_store) {
+            if (!M16) {
+                fragsA(FA1, avc, 1);                            // (this step, k-half 1)
+                fragsB(FB1, u % 3, 1);
+                if (do_req) gloadB(rb[(u + 1) % PD]);
+                mm32(FA0, FB0);
+                if (++ct >= HT) { ct = 0; ++cc; }
+                hrows(avc, cc & 1, ct);
+                if (has_next) {                                 // (next step, k-half 0)
+                    fragsA(FA0, avc, 0);
+                    fragsB(FB0, (u + 1) % 3, 0);
+                }
+                mm32(FA1, FB1);
+            } else {
+                // 16x16x32: a step is 2 TN column blocks of 16; the A fragments of the whole step are FA0, the next step's
+                // are read into FA1 under the second block and swapped by name below
+                fragsB(FB1, u % 3, 1);
+                if (do_req) gloadB(rb[(u + 1) % PD]);
+                mm16(FA0, FB0, 0);
+                if (++ct >= HT) { ct = 0; ++cc; }
+                int avn[NRB];
+                hrows(avn, cc & 1, ct);
+#pragma unroll
+                for (int nb = 1; nb < 2 * TN; ++nb) {
+                    if (nb + 1 < 2 * TN) fragsB((nb & 1) ? FB0 : FB1, u % 3, nb + 1);
+                    else if (has_next) fragsB((nb & 1) ? FB0 : FB1, (u + 1) % 3, 0);
+                    if (nb == 1 && has_next) fragsA(FA1, avn, 0);
+                    mm16(FA0, (nb & 1) ? FB1 : FB0, nb);
+                }
+#pragma unroll
+                for (int b2 = 0; b2 < NRB; ++b2) {
+                    FA0[b2][0] = FA1[b2][0];
+                    FA0[b2][1] = FA1[b2][1];
+                    avc[b2] = avn[b2];
+                }
+            }
+            if (do_store) lstoreB((u + 2) % 3, rb[(u + 2) % PD]);
+            // the halo stream: store the item requested HD steps ago (into the NEXT chunk's buffer: nobody reads it before the
+            // barrier that ends step 7 of this chunk; slot 8 is always a sink slot because R <= 512), then reuse its registers
+            // for a new request.  Items past the last chunk read the zero page and land in the sink row: no conditional
+            // request or store in the stream.
+            hstore(hv[u % HD], sc, ss);
+            if (++ss >= HT) { ss = 0; ++sc; }
+            hv[u % HD] = hload(hc, hs);
+            if (++hs >= HT) { hs = 0; ++hc; }
+            __syncthreads();
+        };
+        int ks = 0;
+        for (; ks + UNH + PD + 1 <= nks; ks += UNH) {
+#pragma unroll
+            for (int u = 0; u < UNH; ++u) hstep(u, true, true, true);
+        }
+        for (; ks < nks; ks += UNH) {
+#pragma unroll
+            for (int u = 0; u < UNH; ++u)
+                if (ks + u < nks) hstep(u, ks + u + 1 < nks, ks + u + PD + 1 < nks, ks + u + 2 < nks);
+        }
+    } else {
     gload(ra[0], rb[0]);
     STAMP(2);
     lstore(0, ra[0], rb[0]);
     __syncthreads();
     STAMP(3);
     // timing probes (compile with -DVD_PROBE=bits; results are garbage): bit0 skip the global loads, bit1 skip the
-    // LDS stores (and the operand split), bit2 skip the per-step barrier
+    // LDS stores (and the operand split), bit2 skip the per-step barrier, bit3 / bit4 every activation / weight request
+    // reads the resident zero page (the requests are issued, the memory system is not exercised)
     constexpr bool ld = !(VD_PROBE & 1), st = !(VD_PROBE & 2), bar = !(VD_PROBE & 4);
     // PD K-steps of global-load latency cover with PD register sets (tile t lives in set t % PD): tile ks+PD is
     // requested while tile ks is multiplied, and the registers of tile ks+1 (requested PD-1 steps earlier, so the
@@ -557,6 +828,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         }
     }
 
+    }   // !HALO
     STAMP(4);
     if (NPL == 2) {                    // undo the two operand scales: an exact power of two
         const int de = -(sexp_a + sexp_b);
@@ -904,8 +1176,23 @@ const float* zero_page() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO = false>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s);
+
+// LDS bytes of the halo loop for a BM x BN tile on a map of width W: two halo buffers of BM + 2 (W + 1) rows (+ zero row
+// + sink row) and a ring of three weight stages, 128 B per row
+inline int64_t halo_lds_bytes(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 2) * 128 + 3ll * BN * 128; }
+
+// 3x3 stride-1 'same' geometry (forward, or the data gradient of such a conv), halo within the LDS and the 9 x 64-row
+// slots of the halo stream
+inline bool halo_ok(const vd_conv_desc& d, int BM, int BN) {
+    if (!(d.flags & VD_MATH_F16X2) || (d.flags & VD_MATH_NOHALO) || d.in_scale || d.T != 9 || d.in_stride != 1 || d.Kfr != 1 ||
+        d.Hg != d.Hi || d.Wg != d.Wi || BN < 64)
+        return false;
+    for (int t = 0; t < 9; ++t)
+        if (d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1 || d.dz[t] != 0) return false;
+    return BM + 2 * (d.Wi + 1) <= 8 * 64 && halo_lds_bytes(BM, BN, d.Wi) <= 160 * 1024;     // 8 stream slots + 1 idle (see hstep)
+}
 
 template <int WM, int WN, int TM, int TN, bool XF, bool SP = false, bool M16 = false>
 int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
@@ -915,6 +1202,11 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
         return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 1 : 3>(d, s);
     }
     if (SP && (d.flags & VD_MATH_F16X2)) {         // two fp16 planes, three MFMAs per product block; no XF variant
+        constexpr bool HT_ = SP && WM * WN == 8 && WN * TN * 32 >= 64;     // tiles the halo loop is instantiated for
+        if (HT_ && halo_ok(d, WM * TM * 32, WN * TN * 32)) {
+            if (d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, SP ? 2 : 3, HT_>(d, s);
+            return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 2 : 3, HT_>(d, s);
+        }
         if (d.bs_part) return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, true, SP ? 2 : 3>(d, s);
         return launch_igemm_bs<WM, WN, TM, TN, false, SP, M16, false, SP ? 2 : 3>(d, s);
     }
@@ -922,17 +1214,23 @@ int launch_igemm(const vd_conv_desc& d, hipStream_t s) {
     return launch_igemm_bs<WM, WN, TM, TN, XF, SP, M16, false, 3>(d, s);
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds0 = SP ? 2 * (BM + BN) * NPL * 64 : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
     constexpr int lds_epi = WM * WN * 32 * LDS_LD * 4 > WM * BN * 2 * 4 ? WM * WN * 32 * LDS_LD * 4 : WM * BN * 2 * 4;
-    constexpr int lds = lds0 > lds_epi ? lds0 : lds_epi;       // operand stages, or the epilogue patches if larger
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr int lds_fixed = lds0 > lds_epi ? lds0 : lds_epi;       // operand stages, or the epilogue patches if larger
+    static_assert(lds_fixed <= 160 * 1024, "LDS budget");
+    int lds = lds_fixed;
+    if (HALO) {
+        const int64_t hb = halo_lds_bytes(BM, BN, d.Wi);
+        lds = hb > lds_epi ? (int)hb : lds_epi;
+    }
     static bool attr_done = false;
-    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS, NPL>;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS, NPL, HALO>;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HALO ? 160 * 1024 : lds_fixed);
         attr_done = true;
     }
     const int64_t M = (int64_t)d.N * d.Hg * d.Wg;

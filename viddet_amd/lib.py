@@ -15,6 +15,7 @@ EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
 MATH_BF16 = 32         # products on bf16-rounded operands (one MFMA term), fp32 tensors and accumulation
 MATH_F16X2 = 64        # two-way fp16 operand split with per-tensor power-of-two scales (three MFMA terms, fp32-accurate)
+MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-staged one (A/B timing)
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 

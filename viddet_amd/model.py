@@ -94,7 +94,8 @@ class Program:
                 e1.record()
                 if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
                     meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT),
-                                bf16=bool(args[0]._obj.flags & L.MATH_BF16), f16x2=bool(args[0]._obj.flags & L.MATH_F16X2))
+                                bf16=bool(args[0]._obj.flags & L.MATH_BF16), f16x2=bool(args[0]._obj.flags & L.MATH_F16X2),
+                                nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO))
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
@@ -121,7 +122,7 @@ _MATH_OVERRIDE = [None]
 # 'split2' = two-way fp16 operand split with per-tensor power-of-two scales (VD_MATH_F16X2: three MFMAs per product block
 # instead of six, fp32-accurate); 'auto' times native, split and split2 per launch record
 _MATH_MODES = ("native", "split", "split2", "auto", "bf16")
-_ALL_MATH = L.MATH_SPLIT | L.MATH_BF16 | L.MATH_F16X2
+_ALL_MATH = L.MATH_SPLIT | L.MATH_BF16 | L.MATH_F16X2 | L.MATH_NOHALO
 
 
 def set_conv_math(mode):
@@ -134,6 +135,7 @@ def set_conv_math(mode):
 
 def _tile_candidates(d, math):
     """(flags bit, tile) candidates of one launch record."""
+    import os
     cands = []
     if math in ("native", "auto"):
         if d.Co <= 32:
@@ -150,6 +152,9 @@ def _tile_candidates(d, math):
         fls.append(L.MATH_F16X2 if (d.amax_in and d.amax_w and not d.in_scale) else L.MATH_SPLIT)
     if math == "bf16":
         fls.append(L.MATH_BF16)
+    # the halo-staged loop (3x3 stride-1 geometry) is timed against the generic one
+    if L.MATH_F16X2 in fls and os.environ.get("VD_HALO_AB", "1") == "1" and d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Co > 32:
+        fls.append(L.MATH_F16X2 | L.MATH_NOHALO)
     for fl in dict.fromkeys(fls):
         if d.Co <= 32:           # 256 x 32 tiles (9: 32x32x16 MFMA, 10: 16x16x32)
             cands += [(fl, t) for t in (9, 10)]

@@ -10,7 +10,7 @@ import torch
 
 from . import lib as L
 from .lib import (ConvDesc, WgradDesc, HeadDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL, MATH_SPLIT, MATH_BF16, MATH_F16X2,
-                  AMAX_FLOATS, check, ptr)
+                  MATH_NOHALO, AMAX_FLOATS, check, ptr)
 
 
 def round_up(v, m):
@@ -99,8 +99,8 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
         flags |= EPI_LEAKY
     if residual is not None:
         flags |= EPI_RESIDUAL
-    if split == 'f16x2':
-        flags |= MATH_F16X2
+    if split in ('f16x2', 'f16x2nh'):           # 'f16x2nh': without the halo-staged loop of the 3x3 stride-1 convs
+        flags |= MATH_F16X2 | (MATH_NOHALO if split == 'f16x2nh' else 0)
         amax_in = amax(x) if amax_in is None else amax_in
         amax_w = amax(wp) if amax_w is None else amax_w
         d.amax_in, d.amax_w = ptr(amax_in), ptr(amax_w)
@@ -139,7 +139,7 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
-    if split == 'f16x2':
+    if split in ('f16x2', 'f16x2nh'):
         d.flags = MATH_F16X2
         amax_in = amax(x) if amax_in is None else amax_in
         amax_dout = amax(dout) if amax_dout is None else amax_dout
