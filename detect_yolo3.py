@@ -83,7 +83,7 @@ def detect(net, dataset, loader, max_do=-1):
     c = 0
     for x, _label, sidxs in loader:
         ids, scores, bboxes = net(torch.from_numpy(x).cuda())
-        W = x.shape[-1]
+        W = x.shape[-2] if x.dtype == np.uint8 else x.shape[-1]           # uint8 frames are (B,H,W,3)
         ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
         bboxes = np.clip(bboxes.cpu().numpy(), 0, W)                       # :228 clip to image size
         for id_, score, box, sidx in zip(ids, scores, bboxes, sidxs):
@@ -157,8 +157,9 @@ def main(argv=None):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     name = FLAGS.dataset[0]
     dataset = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples)
-    loader = Loader(dataset, YOLO3VideoInferenceTransform(FLAGS.data_shape, FLAGS.data_shape), FLAGS.batch_size,
-                    train=False, last_batch="keep", rank=rank, world=world)
+    # frames travel as uint8 and are normalised on the device (vd_preprocess_u8_nchw: the transform's own arithmetic)
+    loader = Loader(dataset, YOLO3VideoInferenceTransform(FLAGS.data_shape, FLAGS.data_shape, device_normalize=True),
+                    FLAGS.batch_size, train=False, last_batch="keep", rank=rank, world=world)
     # detect_yolo3.py:871-892
     net = yolo3_darknet53(dataset.classes, pretrained_base=False, k=FLAGS.window[0], k_join_type=FLAGS.k_join_type,
                           k_join_pos=FLAGS.k_join_pos, block_conv_type=FLAGS.block_conv_type)

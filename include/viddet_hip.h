@@ -276,6 +276,9 @@ int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute,
 int vd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, void* stream);
 /* transforms.py:229-245: uint8 HWC -> /255 -> (x-mean)/std, NHWC fp32 */
 int vd_preprocess_u8_nhwc(const uint8_t* in, float* out, int64_t npix, void* stream);
+/* the same arithmetic from uint8 NHWC frames [N,H,W,3] into the planar fp32 batch [N,3,H,W] the network takes
+ * (transforms.py:239-245 to_tensor + normalize): loaders ship uint8, a quarter of the bytes */
+int vd_preprocess_u8_nchw(const uint8_t* in, float* out, int N, int H, int W, void* stream);
 /* layers.py:161-205 TemporalPooling over K frames: x [B,K,HW*C] -> y [B,HW*C]; type 0=max 1=mean */
 int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, int64_t inner, int type,
                      void* stream);

@@ -217,6 +217,28 @@ def test_wd_mult_and_lr_mult_are_applied():
     assert len(net._optimizer_ranges()) >= 4
 
 
+def test_uint8_frames_are_normalised_on_the_device():
+    """Loaders ship uint8 (B,H,W,3) frames; vd_preprocess_u8_nchw does transforms.py:239-245 (to_tensor: /255, normalize:
+    (x - mean) / std, HWC -> CHW) on the GPU.  The planar batch equals the oracle's preprocessing, and the detections are
+    BIT-IDENTICAL to feeding the host-normalised fp32 batch."""
+    from viddet_amd.data import _to_tensor_normalize
+    net, P = _mk_net(4, 12, obj_bias=-1.0)
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    a = [t.clone() for t in net(torch.from_numpy(img).cuda())]
+    inbuf = net._programs[('buf', 2, 64, 64, False)]['in'].cpu().numpy()
+    ref = np.stack([R.preprocess_u8(img[i]) for i in range(2)])
+    assert maxdiff(inbuf, ref) < 1e-6
+    host = np.stack([_to_tensor_normalize(img[i]) for i in range(2)])
+    assert np.array_equal(inbuf, host)                      # the same fp32 operations in the same order
+    b_ = net(torch.from_numpy(host).cuda())
+    torch.cuda.synchronize()
+    for u, v in zip(a, b_):
+        assert torch.equal(u, v)
+    with pytest.raises(ValueError):
+        net(torch.from_numpy(img[:, :, :, :2].copy()).cuda())
+
+
 def test_reset_class_reuses_rows():
     net, P = _mk_net(4, 7, obj_bias=0.0)
     old = net.collect_params()["yolo_outputs.0.prediction.weight"].data().cpu().numpy()

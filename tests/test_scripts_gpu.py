@@ -125,6 +125,7 @@ def test_train_script_steps_equal_the_protocol_loop(tmp_path, monkeypatch, no_wd
     from viddet_amd import model as M
     from viddet_amd.data import SyntheticDetection, YOLO3VideoTrainTransform, Loader
     from viddet_amd.model import yolo3_darknet53
+    from viddet_amd.video import Rng
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("VD_AUTOTUNE", "0")
     M._TUNE_CACHE.clear()
@@ -134,7 +135,7 @@ def test_train_script_steps_equal_the_protocol_loop(tmp_path, monkeypatch, no_wd
     net = T.main(args)
     # the batches the script saw: same dataset, transform and loader seeds (train_yolov3.py get_dataset / get_dataloader)
     ds = SyntheticDetection("voc", num_samples=bs, seed=seed)
-    loader = Loader(ds, YOLO3VideoTrainTransform(size, size, ds.num_class, np.random.default_rng(seed)), bs, train=True,
+    loader = Loader(ds, YOLO3VideoTrainTransform(size, size, ds.num_class, Rng.seeded(seed)), bs, train=True,
                     shuffle=True, seed=seed)
     ref = yolo3_darknet53(ds.classes)
     ref.initialize(init="he", seed=seed)

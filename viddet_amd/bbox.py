@@ -149,10 +149,13 @@ _SSD_CONSTRAINTS = ((0.1, None), (0.3, None), (0.5, None), (0.7, None), (0.9, No
 
 
 def random_crop_with_constraints(bboxs, size, min_scale=0.3, max_scale=1, max_aspect_ratio=2, constraints=None,
-                                 max_trial=50):
+                                 max_trial=50, py_rng=None, np_rng=None):
     """SSD-style constrained random crop (models/transforms/bbox.py:13-128).  Consumes python's `random`
     for the trials and numpy's global RNG for the final pick, in the reference's order, so that a fixed
-    (random.seed, np.random.seed) pair reproduces the reference's crop."""
+    (random.seed, np.random.seed) pair reproduces the reference's crop.  py_rng / np_rng: private generators with the
+    same methods (random.Random / numpy RandomState) instead of the two global ones."""
+    random = py_rng if py_rng is not None else globals()['random']
+    nprand = np_rng if np_rng is not None else np.random
     constraints = _SSD_CONSTRAINTS if constraints is None else constraints
     w, h = size
     single = not isinstance(bboxs, list)
@@ -180,6 +183,6 @@ def random_crop_with_constraints(bboxs, size, min_scale=0.3, max_scale=1, max_as
             if ok:
                 candidates.append((left, top, cw, ch))
                 break
-    pick = candidates.pop(np.random.randint(0, len(candidates)))
+    pick = candidates.pop(nprand.randint(0, len(candidates)))
     cropped = crop(frames, pick, allow_outside_center=False)
     return cropped, (pick[0], pick[1], pick[2], pick[3])

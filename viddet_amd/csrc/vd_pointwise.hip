@@ -144,6 +144,17 @@ __global__ void k_preprocess_u8(const uint8_t* __restrict__ in, float* __restric
     }
 }
 
+// the same arithmetic, written as the planar [N,3,H,W] batch the stem kernel reads (vd_stem.hip): one thread = one pixel
+__global__ void k_preprocess_u8_nchw(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t npix, int64_t hw) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    GRID_STRIDE(i, npix) {
+        const int64_t n = i / hw, r = i - n * hw;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(n * 3 + c) * hw + r] = ((float)in[i * 3 + c] / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
 __global__ void k_tpool(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg, int B,
                         int K, int64_t inner, int type) {
     const int64_t total = (int64_t)B * inner;
@@ -313,6 +324,14 @@ int vd_preprocess_u8_nhwc(const uint8_t* in, float* out, int64_t npix, void* str
     VD_REQUIRE(in && out && npix > 0, "vd_preprocess_u8_nhwc: bad args");
     hipLaunchKernelGGL(k_preprocess_u8, dim3(sblocks(npix * 3)), dim3(256), 0, (hipStream_t)stream, in, out, npix * 3);
     VD_CHECK_LAUNCH("vd_preprocess_u8_nhwc");
+    return VD_OK;
+}
+
+int vd_preprocess_u8_nchw(const uint8_t* in, float* out, int N, int H, int W, void* stream) {
+    VD_REQUIRE(in && out && N > 0 && H > 0 && W > 0, "vd_preprocess_u8_nchw: bad args");
+    const int64_t hw = (int64_t)H * W;
+    hipLaunchKernelGGL(k_preprocess_u8_nchw, dim3(sblocks(N * hw)), dim3(256), 0, (hipStream_t)stream, in, out, N * hw, hw);
+    VD_CHECK_LAUNCH("vd_preprocess_u8_nchw");
     return VD_OK;
 }
 

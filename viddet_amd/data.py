@@ -2,7 +2,7 @@
 
 Mirrors (paths under /root/reference):
   Dataset.__getitem__ -> (img HWC uint8, label (N,6) [x1,y1,x2,y2,cls,difficult])   datasets/pascalvoc.py:94-127
-  YOLO3VideoTrainTransform.__call__       models/definitions/yolo/transforms.py:199-294  (fixed-shape path)
+  YOLO3VideoTrainTransform.__call__       models/definitions/yolo/transforms.py:199-294  (the full augmentation chain)
   YOLO3VideoInferenceTransform.__call__   models/definitions/yolo/transforms.py:316-350
   batchify: Stack images/targets, Pad(-1) gt boxes                                   train_yolov3.py:252-256
 The real file-system readers (VOC/COCO/DET/VID) are out of scope: no dataset files
@@ -12,6 +12,7 @@ import numpy as np
 
 from . import bbox as tbbox
 from .targets import prefetch_targets
+from .video import Rng, imresize, random_color_distort, random_expand
 
 NUM_CLASSES = {"voc": 20, "coco": 80, "det": 200, "vid": 30, "comb": 285, "synthetic": 20}
 MEAN = np.array([0.485, 0.456, 0.406], np.float32)     # transforms.py:167
@@ -59,33 +60,28 @@ class SyntheticDetection:
         return imgs, frames[self._window // 2][1]
 
 
-def _resize_nearest(img, w, h):
-    """Host resize to (h,w).  The reference uses mx.image.imresize (interp 9 / random 0-4, transforms.py:229,332),
-    an OpenCV call that is not reproducible offline; nearest sampling keeps the pipeline self-contained."""
-    ih, iw = img.shape[:2]
-    ys = np.minimum((np.arange(h) * (ih / h)).astype(np.int64), ih - 1)
-    xs = np.minimum((np.arange(w) * (iw / w)).astype(np.int64), iw - 1)
-    return img[ys][:, xs]
-
-
 def _to_tensor_normalize(img):
-    x = img.astype(np.float32) / 255.0            # mx.nd.image.to_tensor
+    x = img.astype(np.float32) / 255.0            # mx.nd.image.to_tensor (any input dtype is divided by 255)
     x = (x - MEAN) / STD                          # mx.nd.image.normalize
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 
 
 class YOLO3VideoInferenceTransform:
-    """transforms.py:297-350: resize to (width,height), to_tensor, normalize; boxes resized along."""
+    """transforms.py:297-350: resize to (width,height) with interp 9 (area when shrinking / bicubic when enlarging,
+    viddet_amd/video.py imresize), to_tensor, normalize; boxes resized along.  device_normalize=True keeps the resized
+    frames as uint8 (H,W,3) / (k,H,W,3): the network normalises them on the GPU (vd_preprocess_u8_nchw) - the same
+    arithmetic, a quarter of the bytes over PCIe."""
 
-    def __init__(self, width, height):
-        self._w, self._h = width, height
+    def __init__(self, width, height, device_normalize=False):
+        self._w, self._h, self._u8 = width, height, device_normalize
 
     def __call__(self, img, label, idx=0):
         h, w = img.shape[-3], img.shape[-2]
-        if img.ndim == 4:                                  # (k,h,w,c) window -> (k,3,H,W)   transforms.py:322-343
-            out = np.stack([_to_tensor_normalize(_resize_nearest(f, self._w, self._h)) for f in img])
-        else:
-            out = _to_tensor_normalize(_resize_nearest(img, self._w, self._h))
+        frames = img if img.ndim == 4 else img[np.newaxis]
+        ims = [imresize(f, self._w, self._h, interp=9) for f in frames]                      # transforms.py:329-333
+        out = np.stack(ims) if self._u8 else np.stack([_to_tensor_normalize(im) for im in ims])
+        if img.ndim != 4:
+            out = out[0]
         bb = tbbox.resize(label, (w, h), (self._w, self._h))
         if isinstance(bb, (list, tuple)):                  # per-frame labels (--mult_out): (k, M, 6), -1 padded
             return out, pad_stack([np.asarray(b, dtype=np.float32) for b in bb]), idx
@@ -93,32 +89,58 @@ class YOLO3VideoInferenceTransform:
 
 
 class YOLO3VideoTrainTransform:
-    """transforms.py:143-294, fixed-shape path: random horizontal flip, resize, normalise, prefetch targets."""
+    """transforms.py:143-294, the whole augmentation chain in the reference's order (:199-246): random colour distortion,
+    random expansion (probability 0.5, canvas filled with the dataset mean) with the boxes translated, SSD-style
+    constrained random crop, resize with a random interpolation (0-4), random horizontal flip (0.5), to_tensor +
+    normalise, then the prefetch targets (:252-294).  One set of decisions per sample: every frame of a window gets the
+    same distortion / crop / flip.  `rng`: viddet_amd.video.Rng (numpy + python generators; default = a private pair
+    seeded with 0; Rng() = the global modules, exactly the reference's sources)."""
 
-    def __init__(self, width, height, num_class, rng=None):
+    def __init__(self, width, height, num_class, rng=None, augment=True, device_normalize=False):
         self._w, self._h, self._c = width, height, num_class
-        self._rng = np.random.default_rng(0) if rng is None else rng
+        if rng is None:
+            rng = Rng.seeded(0)
+        elif isinstance(rng, np.random.Generator):             # an older call form: derive the pair from the generator
+            rng = Rng.seeded(int(rng.integers(0, 2 ** 31 - 1)))
+        self._rng, self._augment, self._u8 = rng, augment, device_normalize
 
     def __call__(self, img, label):
-        h, w = img.shape[-3], img.shape[-2]
-        bb = tbbox.resize(label, (w, h), (self._w, self._h))
-        frames = img if img.ndim == 4 else img[np.newaxis]             # (k,h,w,c); one flip decision per window
-        ims = [_resize_nearest(f, self._w, self._h) for f in frames]
-        if self._rng.random() < 0.5:                                  # transforms.py:233-236
+        rng = self._rng
+        frames = (img if img.ndim == 4 else img[np.newaxis])
+        bb = label
+        if self._augment:
+            frames = random_color_distort(frames, rng=rng)                                   # :207 (float32 from here on)
+            if rng.np.uniform(0, 1) > 0.5:                                                   # :210-214
+                frames, expand = random_expand(frames, fill=[m * 255 for m in MEAN], rng=rng)
+                bb = tbbox.translate(bb, x_offset=expand[0], y_offset=expand[1])
+            k, h, w, c = frames.shape                                                        # :217-220
+            bb, crop = tbbox.random_crop_with_constraints(bb, (w, h), py_rng=rng.py, np_rng=rng.np)
+            x0, y0, cw, ch = crop
+            frames = frames[:, y0:y0 + ch, x0:x0 + cw, :]
+        k, h, w, c = frames.shape
+        interp = int(rng.np.randint(0, 5)) if self._augment else 1                           # :224
+        ims = [imresize(f, self._w, self._h, interp=interp) for f in frames]
+        bb = tbbox.resize(bb, (w, h), (self._w, self._h))
+        if rng.np.uniform(0, 1) > 0.5:                                                       # :233-236
             ims = [im[:, ::-1] for im in ims]
             bb = tbbox.flip(bb, (self._w, self._h), flip_x=True)
-        x = np.stack([_to_tensor_normalize(im) for im in ims])
+        if self._u8:          # device-side normalisation: round the (possibly distorted, float) frames to uint8 first
+            x = np.stack([np.clip(np.rint(im), 0, 255).astype(np.uint8) for im in ims])
+        else:
+            x = np.stack([_to_tensor_normalize(im) for im in ims])
         if img.ndim != 4:
             x = x[0]
-        if isinstance(bb, (list, tuple)):
+        bboxs = list(bb) if isinstance(bb, (list, tuple)) else [bb]       # the crop returns a list of per-frame arrays
+        if len(bboxs) > 1:
             # per-frame labels (--mult_out, transforms.py:252-294): targets of every frame stacked on a leading t axis,
             # gt boxes (t, M, 4) padded with -1
-            tg = [prefetch_targets(self._h, self._w, b[np.newaxis, :, :4], b[np.newaxis, :, 4:5], self._c) for b in bb]
+            tg = [prefetch_targets(self._h, self._w, b[np.newaxis, :, :4], b[np.newaxis, :, 4:5], self._c) for b in bboxs]
             cols = [np.concatenate([t[i] for t in tg], axis=0) for i in range(5)]
-            gt = pad_stack([np.asarray(b[:, :4], dtype=np.float32) for b in bb])
+            gt = pad_stack([np.asarray(b[:, :4], dtype=np.float32) for b in bboxs])
             return (x,) + tuple(cols) + (gt,)
-        gt = bb[np.newaxis, :, :4]
-        ids = bb[np.newaxis, :, 4:5]
+        b0 = np.asarray(bboxs[0])                                         # :269-271 one label set: un-stacked targets
+        gt = b0[np.newaxis, :, :4]
+        ids = b0[np.newaxis, :, 4:5]
         obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c)
         return x, obj[0], ctr[0], scl[0], wgt[0], cls[0], gt[0].astype(np.float32)
 

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vd_stem_wgrad_ws_bytes": (_i64, [_i, _i, _i]),
     "vd_stem_wgrad": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p]),
     "vd_preprocess_u8_nhwc": (_i, [_p, _p, _i64, _p]),
+    "vd_preprocess_u8_nchw": (_i, [_p, _p, _i, _i, _i, _p]),
     "vd_temporal_pool": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
     "vd_temporal_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
     "vd_temporal_cat": (_i, [_p, _p, _i, _i, _i64, _i, _i, _p]),

@@ -898,6 +898,14 @@ class YOLOV3(object):
         if self.noback:
             for (nm, _, _), t in zip(ROUTE_TENSORS, x):
                 bufs['in:' + nm].copy_(t.reshape(bufs['in:' + nm].shape))
+        elif x.dtype == torch.uint8:
+            # uint8 frames (B,H,W,3) or windows (B,K,H,W,3) straight from the loader: /255, normalise and NHWC -> planar in
+            # one kernel (transforms.py:239-245), a quarter of the host-to-device bytes
+            n_, h_, w_ = bufs['in'].shape[0], bufs['in'].shape[2], bufs['in'].shape[3]
+            assert x.shape[-1] == 3 and x.numel() == n_ * h_ * w_ * 3, "uint8 input must be (B[,K],H,W,3)"
+            xd = x.to(self.device).contiguous()
+            L.check(L.load().vd_preprocess_u8_nchw(xd.data_ptr(), bufs['in'].data_ptr(), n_, h_, w_, L.stream_ptr()),
+                    'vd_preprocess_u8_nchw')
         else:
             bufs['in'].copy_(x.reshape(bufs['in'].shape))
 
@@ -1104,6 +1112,8 @@ class YOLOV3(object):
         """(B, H, W) of the image batch a call refers to (the no-backbone inputs are the stride-8/16/32 maps)."""
         if self.noback:
             return x[0].shape[0], x[0].shape[-2] * 8, x[0].shape[-1] * 8
+        if x.dtype == torch.uint8:                  # (B[,K],H,W,3) frames, normalised on the device
+            return x.shape[0], x.shape[-3], x.shape[-2]
         return x.shape[0], x.shape[-2], x.shape[-1]
 
     def _forward_infer(self, x):
@@ -1695,7 +1705,10 @@ class YOLOV3(object):
             if len(args) != 6:
                 raise TypeError("training call takes (x1, x2, x3, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)")
             return self._forward_train(feats, *args)
-        if self._k > 1:
+        if x.dtype == torch.uint8:
+            if x.dim() != (5 if self._k > 1 else 4) or x.shape[-1] != 3 or (self._k > 1 and x.shape[1] != self._k):
+                raise ValueError("expected uint8 frames (B,%sH,W,3), got %s" % ("%d," % self._k if self._k > 1 else "", tuple(x.shape)))
+        elif self._k > 1:
             if x.dim() != 5 or x.shape[1] != self._k or x.shape[2] != 3:
                 raise ValueError("expected a (B,%d,3,H,W) window batch, got %s" % (self._k, tuple(x.shape)))
         elif x.dim() != 4 or x.shape[1] != 3:
