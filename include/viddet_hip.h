@@ -284,6 +284,10 @@ int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, in
                      void* stream);
 int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int B, int K,
                          int64_t inner, int type, void* stream);
+/* x.slice_axis(axis=1, begin=k0, end=k0+kc) on folded frames (yolo3_temporal.py:437-446): x [B*K, inner] -> y [B*kc, inner];
+ * backward=1 is its gradient (x = dy [B*kc, inner], y = dx [B*K, inner], zero outside the range).  Also how the un-padded
+ * temporal convs of _conv21d(padding=[1,0]) (:329-332) are taken out of the 'same'-padded ones: frames [1, K-1). */
+int vd_frame_slice(const float* x, float* y, int B, int K, int k0, int kc, int64_t inner, int backward, void* stream);
 /* 'cat' join (yolo3.py:1108,1136 reshape (B,K,C,h,w)->(B,K*C,h,w)): NHWC [B*K,hw,C] -> [B,hw,K*C];
  * backward=1 runs the inverse (x = stacked gradient, y = per-frame gradient) */
 int vd_temporal_cat(const float* x, float* y, int B, int K, int64_t hw, int C, int backward, void* stream);

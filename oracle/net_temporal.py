@@ -156,12 +156,17 @@ class TemporalNet(Net):
         return Var(y, (x,), bw)
 
     # ---- _conv3d cell on folded frames (layers.py:73-79 + yolo3.py:256-262 swapaxes)
-    def cell3d(self, name, x, train, pad_d, pad):
+    def cell3d(self, name, x, train, pad_d, pad, stride=1, out_k=None):
+        """out_k: frames per window of the OUTPUT when the temporal conv is not padded (kd - 1 fewer than the input's);
+        stride: spatial stride (the (1,2,2) of the side branches)."""
         P, K = self.P, self.k
+        Ko = K if out_k is None else out_k
         w = P[name + ".0.weight"]
         n, c, h, wd = x.v.shape
         x5 = x.v.reshape(n // K, K, c, h, wd).transpose(0, 2, 1, 3, 4)          # (B,C,K,h,w)
-        z = R.conv3d(x5, w, pad_d, pad)
+        z = R.conv3d(x5, w, pad_d, pad, stride)
+        ho, wo = z.shape[3], z.shape[4]
+        no = (n // K) * Ko
         gamma, beta = P[name + ".1.gamma"], P[name + ".1.beta"]
         if train:
             u, mean, var = R.bn_train(z, gamma, beta)
@@ -171,17 +176,17 @@ class TemporalNet(Net):
             u = R.bn_eval(z, gamma, beta, P[name + ".1.running_mean"], P[name + ".1.running_var"])
         pos = self.mask_override.get(name)          # given folded (B*K,C,h,w); unfold like the data
         if pos is not None:
-            pos = pos.reshape(n // K, K, -1, h, wd).transpose(0, 2, 1, 3, 4)
+            pos = pos.reshape(n // K, Ko, -1, ho, wo).transpose(0, 2, 1, 3, 4)
         if train:
-            self.pre[name] = u.transpose(0, 2, 1, 3, 4).reshape(n, -1, h, wd)
+            self.pre[name] = u.transpose(0, 2, 1, 3, 4).reshape(no, -1, ho, wo)
         y5 = R.leaky(u, pos=pos)
-        y = y5.transpose(0, 2, 1, 3, 4).reshape(n, -1, h, wd)
+        y = y5.transpose(0, 2, 1, 3, 4).reshape(no, -1, ho, wo)
 
         def bw(g):
-            g5 = g.reshape(n // K, K, -1, h, wd).transpose(0, 2, 1, 3, 4)
+            g5 = g.reshape(n // K, Ko, -1, ho, wo).transpose(0, 2, 1, 3, 4)
             du = R.leaky_backward(u, g5, pos=pos)
             dz, dgamma, dbeta = R.bn_train_backward(z, gamma, mean, var, du)
-            dx5, dw = R.conv3d_backward(x5, w, dz, pad_d, pad)
+            dx5, dw = R.conv3d_backward(x5, w, dz, pad_d, pad, stride)
             self.G[name + ".0.weight"] = dw
             self.G[name + ".1.gamma"] = dgamma
             self.G[name + ".1.beta"] = dbeta
@@ -275,5 +280,116 @@ class TemporalOutNet(TemporalNet):
             heads.append(self.head(i, tip, train))                        # TimeDistributed(output): per frame
             if i < 2:
                 t = self.cell(transition(i), x, 1, 1, train)
+                x = self.upcat(t, routes[1 - i])
+        return heads
+
+
+def side_param_shapes(num_class):
+    """Parameters of YOLOV3Temporal(t_out=False, conv=2) (yolo3_temporal.py:326-343): the k = 1 network's, plus the two
+    _conv21d side branches convs1 / convs2 (layers.py:82-89: a (1,3,3) and a (3,1,1) Conv3D cell each)."""
+    from .net import param_shapes as base_shapes
+    S = OrderedDict(base_shapes(num_class))
+    for i, (m, ch) in ((1, (256, 512)), (2, (512, 1024))):
+        S["convs%d.0.0.0.weight" % i] = (m, m, 1, 3, 3)
+        S["convs%d.0.1.0.weight" % i] = (ch, m, 3, 1, 1)
+        for j, c in ((0, m), (1, ch)):
+            for t in ("gamma", "beta", "running_mean", "running_var"):
+                S["convs%d.0.%d.1.%s" % (i, j, t)] = (c,)
+    return S
+
+
+def side_init_params(num_class, seed=0, obj_bias=0.0):
+    rng = np.random.default_rng(seed)
+    P = OrderedDict()
+    for key, shp in side_param_shapes(num_class).items():
+        if key.endswith("weight"):
+            P[key] = rng.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))
+            if "prediction" in key:
+                P[key] *= 0.05
+        elif key.endswith("gamma"):
+            P[key] = rng.uniform(0.2, 0.4, shp) if ".body.1.1." in key and key.startswith("stages") else rng.uniform(0.8, 1.2, shp)
+        elif key.endswith("running_var"):
+            P[key] = rng.uniform(0.8, 1.2, shp)
+        elif key.endswith("bias"):
+            b = rng.standard_normal(shp) * 0.1
+            b.reshape(3, -1)[:, 4] += obj_bias
+            P[key] = b
+        else:
+            P[key] = rng.standard_normal(shp) * 0.1
+    return OrderedDict((kk, v.astype(np.float32).astype(np.float64)) for kk, v in P.items())
+
+
+class TemporalSideNet(TemporalNet):
+    """YOLOV3Temporal with t_out=False (yolo3_temporal.py:436-447): TimeDistributed(stages[0]) on the 5 frames; route 0 =
+    the centre frame; convs1 (a per-frame (1,3,3) stride-(1,2,2) conv cell, then a (3,1,1) conv cell WITHOUT temporal padding:
+    5 -> 3 frames) is added to TimeDistributed(stages[1]) of frames 1..3; route 1 = the middle of those; convs2 takes the 3
+    frames to 1 and is added to stages[2] of that middle frame = route 2.  Neck and heads are the single-frame ones."""
+
+    def __init__(self, P, num_class, t=5):
+        Net.__init__(self, P, num_class)
+        assert t == 5                                                      # :399
+        self.k, self.jt, self.jp, self.bct = t, None, 'side', '2'
+        self.argmax_override, self.argmax_natural = {}, {}
+
+    @staticmethod
+    def frames(x, K, k0, kc):
+        """slice_axis(axis=1, begin=k0, end=k0+kc) on folded frames (B*K,C,h,w) -> (B*kc,C,h,w)."""
+        v5 = x.v.reshape((-1, K) + x.v.shape[1:])
+        y = v5[:, k0:k0 + kc].reshape((-1,) + x.v.shape[1:])
+
+        def bw(g):
+            d5 = np.zeros_like(v5)
+            d5[:, k0:k0 + kc] = g.reshape((-1, kc) + x.v.shape[1:])
+            x.acc(d5.reshape(x.v.shape))
+        return Var(y, (x,), bw)
+
+    @staticmethod
+    def add(a, b):
+        def bw(g):
+            a.acc(g)
+            b.acc(g)
+        return Var(a.v + b.v, (a, b), bw)
+
+    def side(self, i, x, K, train):
+        """_conv21d(channel, t=3, d=3, m, padding=[1,0], stride=[(1,2,2),1]) on K folded frames -> K - 2 frames."""
+        self.k = K                                      # cell3d unfolds with self.k frames per window
+        y = self.cell3d("convs%d.0.0" % i, x, train, 0, 1, stride=2)          # (1,3,3), pad (0,1,1), stride (1,2,2)
+        z = self.cell3d("convs%d.0.1" % i, y, train, 0, 0, out_k=K - 2)       # (3,1,1), pad (0,0,0)
+        self.k = 5
+        return z
+
+    def features(self, x_bk, train):
+        nm = stage_names()
+        b, K = x_bk.shape[:2]
+        x = self.cell(nm(0), Var(x_bk.reshape((b * K,) + x_bk.shape[2:])), 3, 1, train)
+        f = 1
+        routes = []
+        for gi, (nlayer, ch) in enumerate(zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024])):
+            side = None
+            if gi == 3:
+                routes.append(self.frames(x, 5, 2, 1))                     # :437
+                side = self.side(1, x, 5, train)                           # :438
+                x = self.frames(x, 5, 1, 3)                                # :439
+            elif gi == 4:
+                side = self.side(2, x, 3, train)                           # :443
+                x = routes[1]                                              # :444 x.slice_axis(1, 1, 2)
+            x = self.cell(nm(f), x, 3, 2, train)
+            f += 1
+            for _ in range(nlayer):
+                m = self.cell(nm(f) + ".body.0", x, 1, 1, train)
+                x = self.cell(nm(f) + ".body.1", m, 3, 1, train, residual=x)
+                f += 1
+            if side is not None:
+                x = self.add(x, side)                                      # :440,445
+                routes.append(self.frames(x, 3, 1, 1) if gi == 3 else x)   # :441 / :446-447
+        heads = []
+        x = routes[2]
+        for i in range(3):
+            for j in range(5):
+                x = self.cell("yolo_blocks.%d.body.%d" % (i, j), x, 1 if j % 2 == 0 else 3, 1, train)
+            tip = self.cell("yolo_blocks.%d.tip" % i, x, 3, 1, train)
+            heads.append(self.head(i, tip, train))
+            if i < 2:
+                t = self.cell("transitions.%d" % i, x, 1, 1, train)
                 x = self.upcat(t, routes[1 - i])
         return heads

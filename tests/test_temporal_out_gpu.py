@@ -28,7 +28,7 @@ def _mk(bct, c, seed):
 def test_factory_guards():
     from viddet_amd.model import yolo3_darknet53
     with pytest.raises(NotImplementedError):
-        yolo3_darknet53(["a"], k=5, temporal=True)                 # the strided side-branch variant (t_out=False)
+        yolo3_darknet53(["a"], k=5, temporal=True, block_conv_type='3')    # t_out=False squeezes the frame axis: 2-D blocks only
     with pytest.raises(NotImplementedError):
         yolo3_darknet53(["a"], k=5, temporal=True, t_out=True, corr_d=4)
     with pytest.raises(AssertionError):
@@ -103,6 +103,7 @@ def test_temporal_out_inference_and_training(bct):
 @pytest.mark.parametrize("flags", [
     ["--window", "3,1", "--k_join_type", "max", "--k_join_pos", "late"],             # YOLOV3T k=3 (BASELINE configs[3])
     ["--window", "5,1", "--temp", "--mult_out"],                                      # YOLOV3Temporal, per-frame outputs
+    ["--window", "5,1", "--temp"],                                                    # YOLOV3Temporal, one output (side branches)
 ])
 def test_train_script_windows_end_to_end(tmp_path, monkeypatch, flags):
     """train_yolov3.py on synthetic VID windows: loader (window batches, per-frame targets), network, loss logging,
@@ -119,3 +120,53 @@ def test_train_script_windows_end_to_end(tmp_path, monkeypatch, flags):
     if "--mult_out" in flags:
         assert "mAP t=4/5" in logs
     assert glob.glob(os.path.join("models", "experiments", "w", "*.params"))
+
+
+def test_temporal_side_branches_inference_and_training():
+    """YOLOV3Temporal(t_out=False) (--temp without --mult_out; yolo3_temporal.py:326-333,436-447): stages on 5 / 3 / 1 frames,
+    the strided 2+1-D side branches convs1 / convs2 (the second cell of each a (3,1,1) conv WITHOUT temporal padding) added to
+    the stage outputs, centre-frame routes, single-frame neck and heads - against oracle/net_temporal.py TemporalSideNet:
+    heads, identical post-NMS rows, the four per-sample losses, all 234 gradients, running statistics."""
+    from viddet_amd.model import yolo3_darknet53
+    from tests.util import assert_rows_match, take_ranks, device_leaky_masks, check_masks_differ_only_at_ties
+    c, b, size = 3, 2, 64
+    net = yolo3_darknet53(["c%d" % i for i in range(c)], k=T_, temporal=True)
+    P = OT.side_init_params(c, seed=61, obj_bias=-1.0)
+    assert set(P) == set(net.collect_params().keys()), sorted(set(P) ^ set(net.collect_params().keys()))[:6]
+    for k, p in net.collect_params().items():
+        assert tuple(P[k].shape) == p.shape, (k, P[k].shape, p.shape)
+        p.set_data(torch.from_numpy(P[k].astype(np.float32)))
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((b, T_, 3, size, size)).astype(np.float32)
+    onet = OT.TemporalSideNet(P, c)
+    ids_r, sc_r, bx_r, rows_r, heads_r = onet.detect(x.astype(np.float64))
+    ids, sc, bx = net(dev(x))
+    torch.cuda.synchronize()
+    assert tuple(ids.shape) == (b, 100, 1)
+    bufs = net._programs[('buf', b, size, size, False)]
+    for s_, hname in enumerate(net.head_names):
+        got = bufs[hname].cpu().numpy()[..., :3 * (5 + c)]
+        assert got.shape[0] == b and maxdiff(got, np.moveaxis(heads_r[s_], 1, -1)) < 1e-3, "head %d" % s_
+    perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
+    assert np.array_equal(take_ranks(ids, perm), ids_r) and int((ids_r >= 0).sum()) > 0
+    assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 5e-3
+    gt = np.array([[[5., 8., 40., 50.], [-1, -1, -1, -1]], [[10., 12., 30., 28.], [20., 5., 60., 62.]]])
+    gid = np.array([[[1.], [-1.]], [[0.], [2.]]])
+    tg = Y.prefetch_targets(size, size, [size // 32, size // 16, size // 8], gt, gid, c)
+    out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+    net.backward()
+    torch.cuda.synchronize()
+    onet.mask_override = device_leaky_masks(net, net._programs[('buf', b, size, size, True)])
+    losses_r, G, _ = onet.train_step(x.astype(np.float64), gt, *tg)
+    check_masks_differ_only_at_ties(onet.pre, onet.mask_override)
+    for i in range(4):
+        assert np.all(np.abs(out[i].cpu().numpy() - losses_r[i]) <= 2e-3 * np.maximum(1.0, np.abs(losses_r[i]))), i
+    for k, v in onet.new_running.items():
+        assert maxdiff(net.collect_params()[k].data().cpu().numpy(), v) < 1e-4, k
+    bad = []
+    for k, gref in G.items():
+        got = net.collect_params()[k].grad().cpu().numpy()
+        scale = max(1e-3, float(np.abs(gref).max()))
+        if maxdiff(got, gref) / scale >= 5e-3:
+            bad.append((k, maxdiff(got, gref) / scale))
+    assert len(G) == 234 and not bad, bad[:6]

@@ -192,6 +192,27 @@ __global__ void k_tpool_bwd(const float* __restrict__ dy, const int32_t* __restr
 
 // 'cat' join of the K frames (yolo3.py:1108,1136 F.reshape(x,(0,-3,-2)): (B,K,C,h,w) -> (B,K*C,h,w)):
 // NHWC folded [B*K, hw, C] -> [B, hw, K*C] with channel index k*C + c; 16-byte units; fwd = gather, bwd = scatter
+// frames [k0, k0 + kc) of every K-frame window: forward y[b][j] = x[b][k0 + j]; backward (the gradient of that) fills the
+// whole K-frame tensor: dx[b][k] = dy[b][k - k0] inside the range, 0 outside
+__global__ void k_frame_slice(const float* __restrict__ x, float* __restrict__ y, int K, int k0, int kc, int64_t inner4, int bwd,
+                              int64_t total) {
+    GRID_STRIDE(i, total) {
+        const int64_t r = i % inner4;
+        int64_t t = i / inner4;
+        if (!bwd) {                              // i runs over y [B][kc][inner4]
+            const int j = (int)(t % kc);
+            const int64_t b = t / kc;
+            reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(x)[((b * K) + k0 + j) * inner4 + r];
+        } else {                                 // i runs over y = dx [B][K][inner4]; x = dy [B][kc][inner4]
+            const int k = (int)(t % K);
+            const int64_t b = t / K;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k >= k0 && k < k0 + kc) v = reinterpret_cast<const f32x4*>(x)[((b * kc) + k - k0) * inner4 + r];
+            reinterpret_cast<f32x4*>(y)[i] = v;
+        }
+    }
+}
+
 __global__ void k_tcat(const float* __restrict__ x, float* __restrict__ y, int B, int K, int64_t hw, int C4, int bwd) {
     const int64_t total = (int64_t)B * K * hw * C4;
     GRID_STRIDE(i, total) {
@@ -349,6 +370,16 @@ int vd_temporal_pool_bwd(const float* dy, const int32_t* argmax, float* dx, int 
     hipLaunchKernelGGL(k_tpool_bwd, dim3(sblocks((int64_t)B * K * inner)), dim3(256), 0, (hipStream_t)stream, dy, argmax,
                        dx, B, K, inner, type);
     VD_CHECK_LAUNCH("vd_temporal_pool_bwd");
+    return VD_OK;
+}
+
+int vd_frame_slice(const float* x, float* y, int B, int K, int k0, int kc, int64_t inner, int backward, void* stream) {
+    VD_REQUIRE(x && y && B > 0 && K > 0 && k0 >= 0 && kc > 0 && k0 + kc <= K && inner > 0 && inner % 4 == 0,
+               "vd_frame_slice: bad args (K=%d k0=%d kc=%d)", K, k0, kc);
+    const int64_t total = (int64_t)B * (backward ? K : kc) * (inner / 4);
+    hipLaunchKernelGGL(k_frame_slice, dim3(sblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, K, k0, kc, inner / 4,
+                       backward, total);
+    VD_CHECK_LAUNCH("vd_frame_slice");
     return VD_OK;
 }
 

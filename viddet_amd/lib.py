@@ -106,6 +106,7 @@ SIGNATURES = {
     "vd_temporal_pool": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
     "vd_temporal_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
     "vd_temporal_cat": (_i, [_p, _p, _i, _i, _i64, _i, _i, _p]),
+    "vd_frame_slice": (_i, [_p, _p, _i, _i, _i, _i, _i64, _i, _p]),
     "vd_yolo_decode_filter": (_i, [C.POINTER(HeadDesc), _f, _p, _p, C.c_int32, _p, _p]),
     "vd_nms_ws_bytes": (_i64, [_i, _i, _i]),
     "vd_nms_topk": (_i, [C.POINTER(HeadDesc), _p, _p, C.c_int32, _p, _f, _i, _i, _p, _p, _p, _p, _p, _i64, _p]),

@@ -391,6 +391,21 @@ class PoolNode:
         self.type = {'max': 0, 'mean': 1, 'cat': 2}[type_]
 
 
+class SelNode:
+    """x.slice_axis(axis=1, begin=k0, end=k0+kc) on folded frames (yolo3_temporal.py:437-446): frames [k0, k0+kc) of every
+    K-frame window of `src` -> `dst` (kc frames per window)."""
+
+    def __init__(self, name, src, dst, K, k0, kc):
+        self.name, self.src, self.dst, self.K, self.k0, self.kc = name, src, dst, K, k0, kc
+
+
+class AddNode:
+    """dst = a + b (yolo3_temporal.py:440,445: the per-frame stage output plus the strided 2+1-D side branch)."""
+
+    def __init__(self, name, a, b, dst, fr):
+        self.name, self.a, self.b, self.dst, self.fr = name, a, b, dst, fr
+
+
 def _feature_name(f):
     if f < 15:
         return "stages.0.%d" % f
@@ -403,7 +418,7 @@ ROUTE_TENSORS = (('f14', 256, 8), ('f23', 512, 16), ('f28', 1024, 32))   # featu
 
 
 def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_type='2', noback=False,
-                temporal_out=False):
+                temporal_out=False, temporal_side=False):
     """Node list of YOLOV3T over Darknet-53 (wrappers.py:54-58,101-103; three_darknet.py:252-258;
     yolo3.py:1003-1054 wiring, :1095-1177 forward).  k>1: the backbone is TimeDistributed (K frames folded
     into the batch, layers.py:241-250); 'early' joins pool each stage output over K, 'late' joins keep K frames
@@ -415,8 +430,12 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
     # through the backbone, the detection blocks (per frame, or 3-D / 2+1-D convs across the t axis) and its OWN
     # prediction convs - no join; TimeDistributed wrappers are created inside hybrid_forward there, so parameter
     # names carry no `.model`
+    # temporal_side = YOLOV3Temporal with t_out=False (yolo3_temporal.py:326-333,436-447): the three Darknet stages run on
+    # 5, 3 and 1 frames of the window; strided 2+1-D side branches (convs1 / convs2: a per-frame 3x3 stride-2 conv, then a
+    # (3,1,1) conv WITHOUT temporal padding, 5 -> 3 and 3 -> 1 frames) carry the neighbours' features down and are added to
+    # the stage outputs; the routes are the centre frames and the neck / heads are the plain single-frame ones.
     late = K > 1 and (k_join_pos == 'late' or temporal_out)
-    td_names = K > 1 and not temporal_out
+    td_names = K > 1 and not temporal_out and not temporal_side
 
     def T(name, c, div, ld=None, fr=1):
         tensors[name] = (c, div, c if ld is None else ld, fr)
@@ -441,21 +460,57 @@ def build_graph(num_class, k=1, k_join_type=None, k_join_pos=None, block_conv_ty
         nodes.append(ConvNode(sname(0), 'in', cur, 3, 32, 3, 1, 1, stem=True, fr=K))
     f = 1
     div = 1
-    for nlayer, ch in zip([] if noback else [1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
-        nxt = T('f%d' % f, ch, div * 2, fr=K)
-        nodes.append(ConvNode(sname(f), cur, nxt, ch // 2, ch, 3, 2, div, fr=K))
+    sfr = K                                # frames the current Darknet stage runs on
+    side = None                            # output of the side branch to add to the next stage output
+
+    def side_branch(i, src, cin, cout, d, fr):
+        """convs{i} = _conv21d(channel=cout, t=3, d=3, m=cin, padding=[1,0], stride=[(1,2,2),1]) on `src` (fr frames)."""
+        sp = T('cx%d.s' % i, cin, d * 2, fr=fr)
+        n1 = ConvNode("convs%d.0.0" % i, src, sp, cin, cin, 3, 2, d, fr=fr)        # (1,3,3) stride (1,2,2), BN + LeakyReLU
+        n1.conv3d = True
+        nodes.append(n1)
+        out = T('cx%d' % i, cout, d * 2, fr=fr - 2)
+        n2 = ConvNode("convs%d.0.1" % i, sp, out, cin, cout, 1, 1, d * 2, kd=3, fr=fr)   # (3,1,1), no temporal padding
+        n2.tvalid = True
+        nodes.append(n2)
+        return out
+
+    for gi, (nlayer, ch) in enumerate(zip([] if noback else [1, 2, 8, 8, 4], [64, 128, 256, 512, 1024])):
+        if temporal_side and gi in (3, 4):
+            i = gi - 2                                                               # side branch 1 / 2
+            if gi == 3:
+                routes.append(T('r0', tensors[cur][0], div))
+                nodes.append(SelNode('sel.r0', cur, 'r0', sfr, 2, 1))                # :437 the centre frame
+            side = side_branch(i, cur, tensors[cur][0], ch, div, sfr)
+            if gi == 3:
+                nxt = T(cur + '.s', tensors[cur][0], div, fr=3)
+                nodes.append(SelNode('sel.s1', cur, nxt, sfr, 1, 3))                 # :439 frames 1..3
+                cur, sfr = nxt, 3
+            else:
+                cur, sfr = routes[1], 1                                              # :444 frame 1 of 3 (= route 1)
+        nxt = T('f%d' % f, ch, div * 2, fr=sfr)
+        nodes.append(ConvNode(sname(f), cur, nxt, ch // 2, ch, 3, 2, div, fr=sfr))
         cur, div, f = nxt, div * 2, f + 1
         for _ in range(nlayer):
-            mid = T('f%d.m' % f, ch // 2, div, fr=K)
-            nxt = T('f%d' % f, ch, div, fr=K)
+            mid = T('f%d.m' % f, ch // 2, div, fr=sfr)
+            nxt = T('f%d' % f, ch, div, fr=sfr)
             nm = sname(f)
-            nodes.append(ConvNode(nm + ".body.0", cur, mid, ch, ch // 2, 1, 1, div, fr=K))
-            nodes.append(ConvNode(nm + ".body.1", mid, nxt, ch // 2, ch, 3, 1, div, residual=cur, fr=K))
+            nodes.append(ConvNode(nm + ".body.0", cur, mid, ch, ch // 2, 1, 1, div, fr=sfr))
+            nodes.append(ConvNode(nm + ".body.1", mid, nxt, ch // 2, ch, 3, 1, div, residual=cur, fr=sfr))
             cur, f = nxt, f + 1
-        if f in (15, 24, 29):
+        if temporal_side and gi in (3, 4):
+            nxt = T(cur + '.a', ch, div, fr=sfr)
+            nodes.append(AddNode('add.%d' % (gi - 2), cur, side, nxt, sfr))          # :440,445 x = x + cx
+            cur = nxt
+            if gi == 3:
+                routes.append(T('r1', ch, div))
+                nodes.append(SelNode('sel.r1', cur, 'r1', 3, 1, 1))                  # :441 the middle of the three
+            else:
+                routes.append(cur)                                                   # :446 squeeze: one frame left
+        elif f in (15, 24, 29) and not temporal_side:
             routes.append(cur)
     nfr = K if late else 1                 # frames carried through the neck
-    if K > 1 and not late:                 # 'early' join (yolo3.py:1107-1124): pool every route over K
+    if K > 1 and not late and not temporal_side:      # 'early' join (yolo3.py:1107-1124): pool every route over K
         pooled = []
         for i, r in enumerate(routes):
             c_, d_ = tensors[r][0], tensors[r][1]
@@ -533,8 +588,9 @@ class YOLOV3(object):
 
     def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, ignore_iou_thresh=0.7,
                  device="cuda", syncbn_scope=None, process_group=None, k=1, k_join_type=None, k_join_pos=None,
-                 block_conv_type='2', noback=False, temporal_out=False):
+                 block_conv_type='2', noback=False, temporal_out=False, temporal_side=False):
         self._classes = list(classes)
+        self.temporal_side = bool(temporal_side)  # YOLOV3Temporal(t_out=False): strided 2+1-D side branches, one output
         self.temporal_out = bool(temporal_out)   # YOLOV3Temporal(t_out=True): per-frame detections / losses
         self._grad_scale = 1.0                   # d(reported loss)/d(sum of per-sample losses), see _forward_train
         self.noback = bool(noback)               # YOLOV3_noback: net(x1, x2, x3[, targets]) on cached backbone features
@@ -577,7 +633,8 @@ class YOLOV3(object):
         self.num_class = num_class
         self.nodes, self.tensors, self.head_names = build_graph(num_class, self._k, self._k_join_type,
                                                                 self._k_join_pos, self._block_conv_type,
-                                                                noback=self.noback, temporal_out=self.temporal_out)
+                                                                noback=self.noback, temporal_out=self.temporal_out,
+                                                                temporal_side=self.temporal_side)
         self._head_frames = self._k if self.temporal_out else 1
         self.input_tensors = [nm for nm, _, _ in ROUTE_TENSORS] if self.noback else ['in']
         self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
@@ -823,6 +880,13 @@ class YOLOV3(object):
         bufs['amax'] = torch.zeros(len(names) * L.AMAX_FLOATS, device=dev)
         for i, nm in enumerate(names):
             bufs['amax:' + nm] = bufs['amax'][i * L.AMAX_FLOATS:(i + 1) * L.AMAX_FLOATS]
+        for n in self.conv_nodes:
+            if getattr(n, 'tvalid', False):        # the 'same'-padded temporal conv output the valid frames are taken from
+                bufs['zf:' + n.dst] = torch.empty(B * n.fr, H // n.div_out, W // n.div_out, n.cout, device=dev)
+                if train:
+                    bufs['dzf:' + n.dst] = torch.empty_like(bufs['zf:' + n.dst])
+                else:
+                    bufs['zs:' + n.dst] = torch.empty_like(bufs[n.dst])
         if train:
             for n in self.nodes:
                 if isinstance(n, PoolNode) and n.type == 0:
@@ -874,6 +938,18 @@ class YOLOV3(object):
         if amax_out:                                   # inference: the epilogue publishes the max-abs of what it writes
             d.amax_out = bufs['amax:' + n.dst].data_ptr()
         return d
+
+    def _add_sel_add_fwd(self, prog, n, bufs, B):
+        """Forward launches of a SelNode / AddNode (the same in inference and training)."""
+        am = lambda t: bufs['amax:' + t].data_ptr()
+        if isinstance(n, SelNode):
+            xs, o = bufs[n.src], bufs[n.dst]
+            prog.add('vd_frame_slice', xs.data_ptr(), o.data_ptr(), B, n.K, n.k0, n.kc, xs[0].numel(), 0)
+            prog.add('vd_amax_merge', am(n.src), None, am(n.dst))
+        else:
+            a, b_, o = bufs[n.a], bufs[n.b], bufs[n.dst]
+            prog.add('vd_add', a.data_ptr(), b_.data_ptr(), o.data_ptr(), o.numel())
+            prog.add('vd_amax', o.data_ptr(), o.numel(), am(n.dst))
 
     def _add_amax_reset(self, prog, bufs):
         prog.add('vd_fill', bufs['amax'].data_ptr(), 0.0, bufs['amax'].numel())
@@ -929,9 +1005,22 @@ class YOLOV3(object):
                     prog.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), None, B, n.K, o[0].numel(), n.type)
                 prog.add('vd_amax_merge', am(n.src), None, am(n.dst))             # max / mean / stacking: bounded by the source's
                 continue
+            if isinstance(n, (SelNode, AddNode)):
+                self._add_sel_add_fwd(prog, n, bufs, B)
+                continue
             if n.stem:
                 self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True)
                 prog.add('vd_amax', bufs[n.dst].data_ptr(), bufs[n.dst].numel(), am(n.dst))
+                continue
+            if getattr(n, 'tvalid', False):
+                # (3,1,1) conv without temporal padding = frames [1, K-1) of the 'same'-padded one; BatchNorm sees those only
+                zf, zs, o = bufs['zf:' + n.dst], bufs['zs:' + n.dst], bufs[n.dst]
+                d = self._conv_desc(n, bufs, B, H, W, zf)
+                prog.hold(d)
+                prog.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
+                prog.add('vd_frame_slice', zf.data_ptr(), zs.data_ptr(), B, n.fr, 1, n.fr - 2, zf[0].numel(), 0)
+                prog.add('vd_bn_apply_leaky', zs.data_ptr(), n.fold_scale.data_ptr(), n.fold_shift.data_ptr(), None,
+                         o.data_ptr(), o.numel() // n.cout, n.cout, LEAKY_SLOPE, am(n.dst))
                 continue
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
@@ -1258,8 +1347,12 @@ class YOLOV3(object):
                     seg.add('vd_temporal_pool', xs.data_ptr(), o.data_ptr(), am, B, n.K, o[0].numel(), n.type)
                 seg.add('vd_amax_merge', amx(n.src), None, amx(n.dst))
                 continue
+            if isinstance(n, (SelNode, AddNode)):
+                self._add_sel_add_fwd(seg, n, bufs, B)
+                continue
             Ho, Wo = H // n.div_out, W // n.div_out
-            M = B * n.fr * Ho * Wo
+            tvalid = getattr(n, 'tvalid', False)
+            M = B * (n.fr - 2 if tvalid else n.fr) * Ho * Wo
             if n.head:
                 d = self._conv_desc(n, bufs, B, H, W, bufs[n.dst], shift=n.bias)
                 seg.hold(d)
@@ -1274,10 +1367,17 @@ class YOLOV3(object):
                 table_rows = nb
                 d = None
             else:
-                d = self._conv_desc(n, bufs, B, H, W, z)
+                d = self._conv_desc(n, bufs, B, H, W, bufs['zf:' + n.dst] if tvalid else z)
                 seg.hold(d)
             if d is None:
                 pass
+            elif tvalid:
+                # 'same'-padded temporal conv on all frames, the valid ones sliced out, statistics over those
+                zf = bufs['zf:' + n.dst]
+                seg.add('vd_conv_igemm', C.byref(d), meta=self._flops(n, B, H, W, 'fwd'))
+                seg.add('vd_frame_slice', zf.data_ptr(), z.data_ptr(), B, n.fr, 1, n.fr - 2, zf[0].numel(), 0)
+                seg.add('vd_bn_stats', z.data_ptr(), M, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                table_rows = None
             elif self.fuse_bn_stats:
                 table_rows = None
                 # BN statistics ride in the conv epilogue: one row of partial sums per M tile, reduced in fp64
@@ -1363,7 +1463,8 @@ class YOLOV3(object):
         producers = {m.dst: m for m in self.conv_nodes if m.bn}
         consumers = {}
         for m in self.nodes:
-            srcs = [m.src, m.residual] if isinstance(m, ConvNode) else ([m.up, m.route] if isinstance(m, UpcatNode) else [m.src])
+            srcs = [m.src, m.residual] if isinstance(m, ConvNode) else ([m.up, m.route] if isinstance(m, UpcatNode) else
+                                                                          ([m.a, m.b] if isinstance(m, AddNode) else [m.src]))
             for t in srcs:
                 if t:
                     consumers.setdefault(t, []).append(m)
@@ -1378,6 +1479,8 @@ class YOLOV3(object):
                 tgrad[m.dst] = any(self._node_trainable(m)) or tgrad[m.src] or bool(m.residual and tgrad[m.residual])
             elif isinstance(m, UpcatNode):
                 tgrad[m.dst] = tgrad[m.up] or tgrad[m.route]
+            elif isinstance(m, AddNode):
+                tgrad[m.dst] = tgrad[m.a] or tgrad[m.b]
             else:
                 tgrad[m.dst] = tgrad[m.src]
         wtrain = [m for m in self.conv_nodes if self._node_trainable(m)[0]]
@@ -1422,6 +1525,35 @@ class YOLOV3(object):
                     seg.add('vd_upsample2x_concat_bwd', dout.data_ptr(), dup_p, drt_p, B * n.fr,
                             dout.shape[1], dout.shape[2], n.cu, n.cr)
                 continue
+            if isinstance(n, SelNode):
+                if not tgrad[n.src]:
+                    continue
+                assert n.dst in written, n.name
+                materialize(n.dst)
+                dout = bufs['d:' + n.dst]
+                dsrc, acc = grad_into(n.src, 0)
+                target = bufs['tmp'][:dsrc.numel()] if acc else dsrc
+                seg.add('vd_frame_slice', dout.data_ptr(), target.data_ptr(), B, n.K, n.k0, n.kc, dsrc[0].numel(), 1)
+                if acc:
+                    seg.add('vd_add', dsrc.data_ptr(), target.data_ptr(), dsrc.data_ptr(), dsrc.numel())
+                continue
+            if isinstance(n, AddNode):
+                if not tgrad[n.dst]:
+                    continue
+                assert n.dst in written, n.name
+                materialize(n.dst)
+                dout = bufs['d:' + n.dst]
+                for t_ in (n.a, n.b):
+                    if not tgrad[t_]:
+                        continue
+                    dsrc, acc = grad_into(t_, 0)
+                    if acc:
+                        seg.add('vd_add', dsrc.data_ptr(), dout.data_ptr(), dsrc.data_ptr(), dsrc.numel())
+                    else:                      # a copy (the identity form of the BatchNorm apply kernel)
+                        seg.add('vd_bn_apply_leaky', dout.data_ptr(), self._ones(dout.shape[-1]).data_ptr(),
+                                self._zeros(dout.shape[-1]).data_ptr(), None, dsrc.data_ptr(),
+                                dout.numel() // dout.shape[-1], dout.shape[-1], 1.0, None)
+                continue
             if isinstance(n, PoolNode):
                 if not tgrad[n.src]:
                     continue
@@ -1440,7 +1572,8 @@ class YOLOV3(object):
                 continue
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
-            M = B * n.fr * Ho * Wo
+            tvalid = getattr(n, 'tvalid', False)
+            M = B * (n.fr - 2 if tvalid else n.fr) * Ho * Wo
             if not tgrad[n.dst]:
                 continue                   # frozen, and nothing trainable upstream: no gradient is needed here
             w_train, v_train = self._node_trainable(n)
@@ -1464,7 +1597,7 @@ class YOLOV3(object):
                 z = bufs['z:' + n.dst]
                 slot = n_dz[0] % 2
                 n_dz[0] += 1
-                dz = dz_bufs[slot][:M * n.cout].view(B * n.fr, Ho, Wo, n.cout)
+                dz = dz_bufs[slot][:M * n.cout].view(-1, Ho, Wo, n.cout)
                 if n.name not in fused_bwd:
                     seg.add('vd_bn_bwd_reduce', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                             n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(),
@@ -1481,6 +1614,12 @@ class YOLOV3(object):
                 seg.add('vd_bn_bwd_apply', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                         n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE,
                         dz.data_ptr(), amx('dz:' + n.name))
+                if tvalid:
+                    # the gradient of the frame slice: dz of the valid frames, zeros on the two border frames; the conv's
+                    # weight / data gradients then are those of the 'same'-padded conv
+                    dzf = bufs['dzf:' + n.dst]
+                    seg.add('vd_frame_slice', dz.data_ptr(), dzf.data_ptr(), B, n.fr, 1, n.fr - 2, dzf[0].numel(), 1)
+                    dz = dzf
             # weight gradient straight into the gradient arena (same fwd-packed layout as the weights)
             if n.stem and w_train:
                 # both operands straight from global memory: the NCHW batch and dz (vd_stem.hip)
@@ -1801,13 +1940,19 @@ def yolo3_darknet53(classes, pretrained_base=False, norm_layer=None, norm_kwargs
     if temporal or t_out:                                         # wrappers.py:96-98
         if corr_d:
             raise NotImplementedError("YOLOV3Temporal with a correlation branch (corr_d) is outside the built scope")
-        if not t_out:
-            raise NotImplementedError("YOLOV3Temporal without per-frame outputs (the strided 2+1-D side branches, "
-                                      "yolo3_temporal.py:431-441) is not built; use t_out=True")
         assert k == 5, "Currently only support t=5 but will increase to more later"        # yolo3_temporal.py:399
         assert block_conv_type in ('2', '3', '21')
         scope = (norm_kwargs or {}).get('scope', 'all') if norm_layer == 'syncbn' else None
-        net = YOLOV3(classes, syncbn_scope=scope, k=k, block_conv_type=block_conv_type, temporal_out=True, **kwargs)
+        if not t_out:
+            # --temp without --mult_out (yolo3_temporal.py:326-333,436-447): strided 2+1-D side branches, ONE output for the
+            # centre frame.  The detection blocks get the squeezed (B,C,h,w) routes, so only the 2-D blocks are defined
+            # (a 3-D block would be handed a 4-D tensor in the reference as well).
+            if block_conv_type != '2':
+                raise NotImplementedError("YOLOV3Temporal(t_out=False) squeezes the frame axis before the detection blocks: "
+                                          "block_conv_type must be '2'")
+            net = YOLOV3(classes, syncbn_scope=scope, k=k, temporal_side=True, **kwargs)
+        else:
+            net = YOLOV3(classes, syncbn_scope=scope, k=k, block_conv_type=block_conv_type, temporal_out=True, **kwargs)
         if freeze_base:
             for name, p in net.collect_params('stages.*').items():
                 p.grad_req = 'null'
