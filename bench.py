@@ -190,9 +190,33 @@ def main():
             fn()
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) * 1e3, 3)
+        net._dp_stats = {"buckets": 0, "bucket_bytes": 0}
         phases = {"fwd_loss_ms": timed(lambda: net(x, gt, *tgd)), "bwd_ms": timed(net.backward),
                   "allreduce_ms": timed(net.allreduce_grads),
                   "sgd_ms": timed(lambda: net.sgd_step(lr, mom, wd, batch_size=B * world))}
+        if world > 1 or force_dist:
+            # Diagnostics of the gradient exchange (the driver computes scaling efficiency itself from `value`): how much of
+            # the all-reduce the backward pass does NOT hide, and what the fabric delivers on the whole arena.
+            #   bwd_ms above = backward with the bucketed all-reduces queued behind the weight-gradient stream (device-
+            #   synchronised, so it includes their completion); bwd_local_ms = the same backward with the collectives
+            #   suppressed; exposed = (bwd + tail all-reduce) - local.  allreduce_arena_ms = ONE all-reduce of the whole
+            #   gradient arena on an idle GPU; bus GB/s = 2 (N-1)/N x bytes / time (ring convention; 7 xGMI links x ~153 GB/s
+            #   per GPU is the per-link bound to compare with).
+            dp = dict(net._dp_stats)
+            net(x, gt, *tgd)
+            net._dp_suppress = True
+            phases["bwd_local_ms"] = timed(net.backward)
+            net._dp_suppress = False
+            phases["allreduce_exposed_ms"] = round(max(0.0, phases["bwd_ms"] + phases["allreduce_ms"] - phases["bwd_local_ms"]), 3)
+            nbytes = 4 * net.grads.numel()
+            torch.distributed.all_reduce(net.grads)          # warm the communicator on this size
+            t_ar = min(timed(lambda: torch.distributed.all_reduce(net.grads)) for _ in range(3))
+            phases["allreduce_arena_ms"] = t_ar
+            phases["allreduce"] = {"arena_mb": round(nbytes / 1e6, 1), "buckets_per_step": dp["buckets"],
+                                   "bucket_mb": round(dp["bucket_bytes"] / max(1, dp["buckets"]) / 1e6, 1),
+                                   "bus_gb_s": round(2.0 * (world - 1) / max(1, world) * nbytes / (t_ar * 1e-3) / 1e9, 1),
+                                   "algo_gb_s": round(nbytes / (t_ar * 1e-3) / 1e9, 1)}
+            net.grads.zero_()                                  # the diagnostic all-reduces scaled the arena; the step is over
 
     # ---- roofline of the dominant kernel (k_conv_igemm: forward + data-gradient convs), measured live with
     # events on the launch stream over one more step

@@ -261,11 +261,35 @@ def test_data_parallel_two_ranks_equal_one_process():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for dup in ("1", ""):      # duplicate shards: bit-identical step; real shards: the update agrees as a whole
-        env = dict(os.environ, VD_DP_DUP=dup) if dup else {k: v for k, v in os.environ.items() if k != "VD_DP_DUP"}
+    base = {k: v for k, v in os.environ.items() if not k.startswith("VD_DP_")}
+    # duplicate shards: bit-identical step; real shards: the update agrees as a whole; then the BASELINE configs[3] family -
+    # k = 3 windows with the SyncBN scope the reference's --syncbn reaches (stem + stride-2 convs), duplicate shards
+    for extra in (dict(VD_DP_DUP="1"), dict(), dict(VD_DP_DUP="1", VD_DP_K="3", VD_DP_SCOPE="reference"),
+                  dict(VD_DP_K="3")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
-                           text=True, timeout=600, env=env)
-        assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (dup, r.stdout[-800:], r.stderr[-1500:])
+                           text=True, timeout=600, env=dict(base, **extra))
+        assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (extra, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_single_rank_rccl_path_and_exchange_diagnostics():
+    """bench.py with VD_FORCE_DIST=1: the RCCL code path (communicator, bucketed asynchronous all-reduce behind the
+    weight-gradient stream, tail all-reduce) on ONE rank, and the diagnostics the first multi-GPU run will print
+    (buckets per step, exposed all-reduce time, bus GB/s of one all-reduce of the whole gradient arena)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VD_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", VD_BUCKET_MB="8")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--size", "64", "--classes", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    ph = out["phases"]
+    assert out["n_gpus"] == 1 and ph["allreduce"]["buckets_per_step"] >= 4 and ph["allreduce"]["arena_mb"] > 200
+    assert ph["allreduce_exposed_ms"] >= 0 and ph["bwd_local_ms"] > 0 and ph["allreduce"]["algo_gb_s"] > 0
 
 
 @pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6)])
@@ -356,6 +380,46 @@ def test_training_step_in_bf16_products():
         whole = dot / np.sqrt(ng * nr)
         print("bf16-product gradients: whole cosine %.4f, per-tensor mean %.3f min %.3f" % (whole, np.mean(cos), min(cos)))
         assert whole > 0.9 and np.mean(cos) > 0.7 and min(cos) > 0.3, (whole, np.mean(cos), min(cos))
+    finally:
+        M.set_conv_math(None)
+        M._TUNE_CACHE.clear()
+
+
+def test_configs4_shape_combined_classes_bf16_products():
+    """BASELINE configs[4] (combined dataset: 285 classes, 608x608, bf16): the mixed-precision arithmetic built for it
+    (set_conv_math('bf16'): bf16-rounded conv operands, fp32 accumulation / tensors / optimiser) with the 285-class heads
+    (A = 870 channels) - a training step against the fp64 oracle at the bf16 tolerance of
+    test_training_step_in_bf16_products, and one full 608x608 frame through forward, loss, backward and the update."""
+    from viddet_amd import model as M
+    M.set_conv_math("bf16")
+    M._TUNE_CACHE.clear()
+    try:
+        b, c, size, m = 2, 285, 96, 4
+        net, P = _mk_net(c, 16, obj_bias=-1.0)
+        rng = np.random.default_rng(16)
+        x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+        gt, tg = _targets(rng, b, c, size, m)
+        out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+        net.backward()
+        torch.cuda.synchronize()
+        losses_r, G, _ = ON.Net(P, c).train_step(x.astype(np.float64), gt, *tg)
+        for i in range(4):
+            assert np.all(np.abs(out[i].cpu().numpy() - losses_r[i]) <= 3e-2 * np.maximum(1.0, np.abs(losses_r[i]))), i
+        dot = ng = nr = 0.0
+        for k in G.keys():
+            g, r_ = net.collect_params()[k].grad().cpu().numpy().ravel().astype(np.float64), G[k].ravel()
+            dot, ng, nr = dot + float(g @ r_), ng + float(g @ g), nr + float(r_ @ r_)
+        assert dot / np.sqrt(ng * nr) > 0.9
+        size = 608
+        x = rng.standard_normal((1, 3, size, size)).astype(np.float32)
+        gt, tg = _targets(rng, 1, c, size, 8)
+        w0 = net.collect_params()["yolo_outputs.2.prediction.weight"].data().clone()
+        out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+        net.backward()
+        net.sgd_step(lr=1e-3, momentum=0.9, wd=5e-4, batch_size=1)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(o).all()) for o in out) and bool(torch.isfinite(net.weights).all())
+        assert not torch.equal(w0, net.collect_params()["yolo_outputs.2.prediction.weight"].data())
     finally:
         M.set_conv_math(None)
         M._TUNE_CACHE.clear()

@@ -20,11 +20,16 @@ import torch.multiprocessing as mp
 # duplicate-shard form (VD_DP_DUP=1) is bit-identical and the sharded form differs by summation order only (4e-4).
 os.environ.setdefault("VD_AUTOTUNE", "0")
 C, SIZE, PER_RANK = 4, 64, 2
+K = int(os.environ.get("VD_DP_K", "1"))                 # frames per window: 3 = the BASELINE configs[3] family (YOLOV3T, late max join)
+SCOPE = os.environ.get("VD_DP_SCOPE", "all")            # SyncBN scope: 'all', or 'reference' = the six layers --syncbn reaches
 
 
 def make(world):
     from viddet_amd.targets import synthetic_batch, prefetch_targets
-    x, gt, ids = synthetic_batch(PER_RANK * world, SIZE, C, 5)
+    x, gt, ids = synthetic_batch(PER_RANK * world * K, SIZE, C, 5)
+    if K > 1:                                           # windows of K frames; the labels are the centre frame's
+        x = x.reshape(PER_RANK * world, K, 3, SIZE, SIZE)
+        gt, ids = gt.reshape(PER_RANK * world, K, -1, 4)[:, K // 2], ids.reshape(PER_RANK * world, K, -1, 1)[:, K // 2]
     tg = prefetch_targets(SIZE, SIZE, gt, ids, C)
     return x, gt, tg
 
@@ -42,7 +47,8 @@ def one_step(net, x, gt, tg, global_batch):
 def build(syncbn):
     from viddet_amd.model import yolo3_darknet53
     net = yolo3_darknet53(["c%d" % i for i in range(C)], norm_layer="syncbn" if syncbn else None,
-                          norm_kwargs={"scope": "all"} if syncbn else None)
+                          norm_kwargs={"scope": SCOPE} if syncbn else None,
+                          **(dict(k=K, k_join_type="max", k_join_pos="late") if K > 1 else {}))
     net.initialize(init="he", seed=3, obj_bias=-1.0)
     return net
 
@@ -67,6 +73,9 @@ def worker(rank, world, port, ret):
 
 def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    # with the 'reference' scope most layers normalise with their OWN shard's statistics, so one process on the joint batch
+    # is not the same computation: only the duplicate-shard form has a single-process equal
+    assert SCOPE == "all" or os.environ.get("VD_DP_DUP"), "VD_DP_SCOPE=reference needs VD_DP_DUP=1"
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(worker, args=(world, 29533, ret), nprocs=world, join=True)

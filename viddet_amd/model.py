@@ -625,6 +625,7 @@ class YOLOV3(object):
         self.bucket_elems = int(float(_os.environ.get('VD_BUCKET_MB', '32')) * (1 << 18))
         self._pending_reduces = []
         self._reduced_from = 1 << 62
+        self._dp_stats = {'buckets': 0, 'bucket_bytes': 0}     # all-reduce buckets queued since the last reset (bench.py)
         self._bucket_group = None      # second communicator for the gradient buckets when SyncBN collectives exist
         self._build(len(self._classes))
 
@@ -1866,8 +1867,10 @@ class YOLOV3(object):
 
     def _bucket_launcher(self, lo, hi, side):
         def f():
-            if not self._dp_active():
+            if not self._dp_active() or getattr(self, '_dp_suppress', False):     # (bench.py times a collective-free backward)
                 return
+            self._dp_stats['buckets'] += 1
+            self._dp_stats['bucket_bytes'] += 4 * (hi - lo)
             st = side if side is not None else torch.cuda.current_stream()
             with torch.cuda.stream(st):
                 h = torch.distributed.all_reduce(self.grads[lo:hi], group=self._bucket_group or self.process_group,
@@ -1880,7 +1883,7 @@ class YOLOV3(object):
         """kvstore-'local' replacement (train_yolov3.py:530): RCCL sum all-reduce of the flat gradient arena.
         With bucketing (default) the conv-weight range was already queued in ~32 MB pieces during backward();
         here the handles are awaited and the remaining small range (gamma, beta, head bias) is reduced."""
-        if not self._dp_active():
+        if not self._dp_active() or getattr(self, '_dp_suppress', False):
             return
         wt = [m.w_off for m in self.conv_nodes if self._node_trainable(m)[0]]
         wt_lo = min(wt) if wt else self.n_weight             # frozen prefix (freeze_base): zeros, never reduced
