@@ -1,0 +1,17 @@
+#!/bin/bash
+# copy the judged summaries of one refresh_profiles.sh run from gpurun_out/<tag>/ into profiles/ (tracked): tools/collect_profiles.sh r02a
+set -e
+T=$1; O=gpurun_out/$T; P=profiles
+cp $O/train_bench.json $P/${T}_train_b64_416_bench.json
+cp $O/detect_bench.json $P/${T}_detect_b32_608_bench.json
+cp $O/detect_bf16_bench.json $P/${T}_detect_b32_608_bf16_bench.json
+cp $O/train_k3_bench.json $P/${T}_train_k3_b16_416_bench.json
+cp $O/train_bf16products_bench.json $P/${T}_train_b64_416_bf16products_bench.json
+cp $(ls $O/prof_train/*/*_kernel_stats.csv | head -1) $P/${T}_train_b64_416_kernel_stats.csv
+cp $(ls $O/prof_detect_bf16/*/*_kernel_stats.csv | head -1) $P/${T}_detect_b32_608_bf16_kernel_stats.csv
+python tools/summarize_rocprof.py $O/prof_train $P/${T}_train_b64_416_kernel_summary.md
+python tools/summarize_rocprof.py $O/prof_detect_bf16 $P/${T}_detect_b32_608_bf16_kernel_summary.md
+cp $O/pmc_traffic.json $P/${T}_train_b64_416_pmc_traffic.json
+cp $O/train_last_step_kernels.json $P/${T}_train_last_step_kernels.json
+cp $O/train_last_step_kernels_serial.json $P/${T}_train_last_step_kernels_serial.json
+ls -la $P/${T}_*
