@@ -54,24 +54,16 @@ def parse():
 
 
 def cpu_baseline(mode, size, classes):
-    """The NumPy oracle (a port, not MXNet) timed on this box's host cores on ONE frame of the same workload."""
-    from oracle import net as ON
-    from oracle import yolo as Y
-    from viddet_amd.targets import synthetic_batch
-    P = ON.init_params(classes, seed=233, obj_bias=-4.0)
-    x, gt, ids = synthetic_batch(1, size, classes, 233)
-    onet = ON.Net(P, classes)
-    x64 = x.astype(np.float64)
-    t0 = time.time()
-    if mode == "train":
-        tg = Y.prefetch_targets(size, size, [size // 32, size // 16, size // 8], gt.astype(np.float64), ids, classes)
-        onet.train_step(x64, gt.astype(np.float64), *tg)
-        sample = "1 frame %dx%d, fwd+loss+bwd, NumPy fp64 oracle (OpenBLAS threads)" % (size, size)
-    else:
-        onet.detect(x64)
-        sample = "1 frame %dx%d, fwd+decode+NMS, NumPy fp64 oracle (OpenBLAS threads)" % (size, size)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
+    """The network on torch-CPU operators (oneDNN, all host threads; oracle/torch_cpu.py) timed on whole steps of a small
+    batch of the same workload for ~20 s: a port - NOT MXNet, which cannot be installed or shipped; MXNet's CPU
+    backend is the same library family (MKL-DNN)."""
+    from oracle import torch_cpu as TC
+    batch = 8 if mode == "train" else 8
+    fps, n, threads = TC.baseline(mode, size, classes, batch)
+    what = "fwd + 4 losses + bwd + SGD-momentum" if mode == "train" else "fwd + decode + NMS"
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d step(s) of %d frames %dx%d, %s, fp32, torch-CPU operators (oneDNN) + the NumPy oracle's target merge / "
+                      "decode; not MXNet" % (n, batch, size, size, what)}
 
 
 def main():

@@ -59,35 +59,10 @@ def test_bn_leaky_vs_torch():
 
 
 def _torch_net(P, c, x, train):
-    """Independent torch-CPU construction of the same architecture (autograd provides the backward)."""
-    tp = {k: T(v).clone().requires_grad_(not k.endswith(("running_mean", "running_var"))) for k, v in P.items()}
-
-    def cell(name, x, k, s, res=None):
-        z = F.conv2d(x, tp[name + ".0.weight"], stride=s, padding=k // 2)
-        u = F.batch_norm(z, tp[name + ".1.running_mean"].clone(), tp[name + ".1.running_var"].clone(),
-                         tp[name + ".1.gamma"], tp[name + ".1.beta"], training=train, momentum=0.1, eps=1e-5)
-        y = F.leaky_relu(u, 0.1)
-        return y if res is None else y + res
-
-    nm = ON.stage_names()
-    h = cell(nm(0), x, 3, 1)
-    f, routes = 1, []
-    for nl, ch in zip([1, 2, 8, 8, 4], [64, 128, 256, 512, 1024]):
-        h = cell(nm(f), h, 3, 2); f += 1
-        for _ in range(nl):
-            h = cell(nm(f) + ".body.1", cell(nm(f) + ".body.0", h, 1, 1), 3, 1, res=h); f += 1
-        if f in (15, 24, 29):
-            routes.append(h)
-    heads, h = [], routes[2]
-    for i in range(3):
-        for j in range(5):
-            h = cell("yolo_blocks.%d.body.%d" % (i, j), h, 1 if j % 2 == 0 else 3, 1)
-        tip = cell("yolo_blocks.%d.tip" % i, h, 3, 1)
-        heads.append(F.conv2d(tip, tp["yolo_outputs.%d.prediction.weight" % i], tp["yolo_outputs.%d.prediction.bias" % i]))
-        if i < 2:
-            t = cell("transitions.%d" % i, h, 1, 1)
-            h = torch.cat([F.interpolate(t, scale_factor=2, mode="nearest"), routes[1 - i]], dim=1)
-    return heads, tp
+    """Independent torch-CPU construction of the same architecture (oracle/torch_cpu.py; autograd provides the backward)."""
+    from oracle import torch_cpu as TC
+    tp = TC.params(P)
+    return TC.torch_net(tp, x, train), tp
 
 
 def test_network_forward_backward_vs_torch_autograd():
