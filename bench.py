@@ -130,7 +130,7 @@ def main():
         # pass valid_thresh=0.01, and report the bias and the measured pass fraction
         P = 3 * ((S // 32) ** 2 + (S // 16) ** 2 + (S // 8) ** 2)
         best = None
-        for bias in ([a.obj_bias] if a.obj_bias is not None else [-3.0, -3.5, -4.0, -4.5, -5.0, -5.5, -6.0]):
+        for bias in ([a.obj_bias] if a.obj_bias is not None else [-3.0 - 0.25 * i for i in range(13)]):
             for i in range(3):
                 p = net.collect_params()["yolo_outputs.%d.prediction.bias" % i]
                 v = p.data().cpu()

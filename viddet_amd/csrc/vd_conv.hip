@@ -44,6 +44,9 @@ namespace {
 #ifndef VD_KROT
 #define VD_KROT 0
 #endif
+#ifndef VD_HALO_STAGGER
+#define VD_HALO_STAGGER 0
+#endif
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
@@ -116,7 +119,7 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& h, uint2& m, uint2&
 // With s the tensor's power-of-two scale (amax*s in [2^14, 2^15)): h = fp16(x*s), l = fp16(x*s - h), both round-to-
 // nearest; x*s - h is exact in fp32.  A product is accumulated from al*bh, ah*bl, ah*bh (f16 MFMAs, fp32 accumulate);
 // al*bl < 2^-22 |a*b| is dropped.  LDS rows hold the two planes back to back, [h: 32 fp16][l: 32] = 128 B = eight 16-B
-// slots s = 4*plane + chunk, stored at slot s ^ key(row) with key(row) = ((row >> 1) & 7) ^ ((row & 1) << 2): the 16 rows
+// slots s = 4*plane + chunk, stored at slot s ^ key(row) (f16x2_key below): the 16 rows
 // of every ds_read_b128 lane group (both MFMA operand maps) then fall on 16 distinct slots of the 64 banks, and the two
 // rows of a ds_write_b64 lane group on the two halves of the 32 write banks - conflict-free without padding.
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
@@ -138,7 +141,15 @@ __device__ __forceinline__ void split2(const f32x4 v, const float s, uint2& h, u
     h = make_uint2(hh[0], hh[1]); l = make_uint2(ll[0], ll[1]);
 }
 
-__device__ __forceinline__ int f16x2_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
+// M16 (16x16x32 operand map: a ds_read_b128 lane group takes 16 consecutive rows but TWO k-chunks, c for 8 of them and
+// c + 1 for the other 8) needs a key that leaves slot bit 0 alone, or the halo loop's reads at shifted rows collide 2-way for
+// 12 of the 16 row alignments (PMC: SQ_LDS_BANK_CONFLICT 1.2e7 of 1.6e7 LDS cycles on the first halo build); searched by
+// brute force over lane groups x row offsets x planes, both keys are conflict-free for their map at ANY start row and for
+// the ds_write_b64 stores.
+template <bool M16>
+__device__ __forceinline__ int f16x2_key(int row) {
+    return M16 ? ((((row >> 1) & 3) << 1) ^ ((row & 1) << 2)) : (((row >> 1) & 7) ^ ((row & 1) << 2));
+}
 
 template <int NPL>
 __device__ __forceinline__ f32x16 mfma32(const v4i a, const v4i b, const f32x16 c) {
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     };
     auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
         if (SP && NPL == 2) {
-            const int key = f16x2_key(lrow);              // lrow + RPP * i has the same low four bits (RPP = 32 or 64)
+            const int key = f16x2_key<M16>(lrow);              // lrow + RPP * i has the same low four bits (RPP = 32 or 64)
             const int c = (tid & 7) >> 1, half = (tid & 1) << 3;
             const int oh = ((c ^ key) << 4) + half, ol = (((4 + c) ^ key) << 4) + half;
             char* a3 = As3 + buf * BM * SP_ROWB;
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
     auto compute = [&](int buf) {
         if (SP && M16) {
             const int r16 = lane & 15, ch = lane >> 4;              // operand row within a 16-row block, 8-k chunk
-            const int rkey = NPL == 2 ? f16x2_key(r16) : 2 * ((r16 >> 3) & 1);
+            const int rkey = NPL == 2 ? f16x2_key<M16>(r16) : 2 * ((r16 >> 3) & 1);
             // byte offset of plane q's chunk `ch` inside a row
             auto slot = [&](int q) { return NPL == 2 ? (((4 * q + ch) ^ rkey) << 4) : (q * 64 + ((ch ^ rkey) << 4)); };
             const char* a3 = As3 + (buf * BM + wm * TM * 32 + r16) * SP_ROWB;
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         if (SP) {
             const char* a3 = As3 + (buf * BM + wm * TM * 32 + (lane & 31)) * SP_ROWB;
             const char* b3 = Bs3 + (buf * BN + wn * TN * 32 + (lane & 31)) * SP_ROWB;
-            const int swz = NPL == 2 ? f16x2_key(lane & 31) : ((lane >> 2) & 3), hh = lane >> 5;
+            const int swz = NPL == 2 ? f16x2_key<M16>(lane & 31) : ((lane >> 2) & 3), hh = lane >> 5;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 v4i fa[TM][NPL], fb[TN][NPL];
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         }
         const int64_t hoff0 = (m0 - (W + 1) + lrow) * (int64_t)p.Ci + lc4;      // element offset of (slot 0, chunk 0)
         const int64_t hslot = 64ll * p.Ci;                                      // elements between slots
-        const int hkey = f16x2_key(lrow);
+        const int hkey = f16x2_key<M16>(lrow);
         const int hl0 = lrow * 128 + hhalf + ((hcs ^ hkey) << 4);               // LDS byte offset of the h piece, slot 0
         const int hl1 = lrow * 128 + hhalf + (((4 + hcs) ^ hkey) << 4);         // ... of the l piece
         const int hsink = (DROW - lrow) * 128;                                  // hl0 + hsink lies in the sink row
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             if (++bt >= HT) { bt = 0; bc0 += BK; }
         };
         auto lstoreB = [&](int buf, const f32x4 (&rb)[BP]) {
-            const int key = f16x2_key(lrow);
+            const int key = f16x2_key<M16>(lrow);
             const int oh = ((hcs ^ key) << 4) + hhalf, ol = (((4 + hcs) ^ key) << 4) + hhalf;
 #pragma unroll
             for (int i = 0; i < BP; ++i) {
@@ -625,7 +636,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
 #pragma unroll
             for (int b = 0; b < NRB; ++b) {
                 const int j = ((amask[b] >> tap) & 1u) ? jbase[b] + ro : ZROW;
-                av[b] = abuf * ABUF + j * 128 + ((f16x2_key(j) ^ lsel) << 4);
+                av[b] = abuf * ABUF + j * 128 + ((f16x2_key<M16>(j) ^ lsel) << 4);
             }
         };
         // ---- MFMA operand fragments, software-pipelined: a K-step never opens with exposed LDS latency.  The measured
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         // two waves of a SIMD leave the barrier together and wait for their reads together.  Here the reads of half-step
         // h + 1 are issued before the MFMAs of half-step h (for the second half of a step that is the NEXT K-step's first
         // half: its weight tile sits in the third ring slot, stored a step ago and published by the last barrier).
-        const int swz = f16x2_key(lane & (RBS - 1));
+        const int swz = f16x2_key<M16>(lane & (RBS - 1));
         auto fragsA = [&](v4i (&fa)[NRB][2], const int (&av)[NRB], int kc) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -718,7 +729,25 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         v4i FA0[NRB][2], FA1[NRB][2], FB0[M16 ? 1 : TN][2], FB1[M16 ? 1 : TN][2];
         fragsA(FA0, avc, 0);
         fragsB(FB0, 0, 0);
+        // The two waves that share a SIMD (w, w + 4) run a step's two phases in opposite order: the "late" wave stores the
+        // weight tile and its halo item and renews its requests FIRST and multiplies second, so its VALU / LDS phase overlaps
+        // the partner's MFMAs instead of both leaving the barrier into their MFMAs together and both idling the pipe while
+        // they split and store.  Built with -DVD_HALO_STAGGER=1 only: measured +-2 % against the lockstep form on every tile
+        // (gpurun_out r2h), so the default keeps the smaller loop body.
+        const bool late = VD_HALO_STAGGER && (__builtin_amdgcn_readfirstlane(wave) & 4);
+        auto hstores = [&](int u, bool do_store) {
+            if (do_store) lstoreB((u + 2) % 3, rb[(u + 2) % PD]);
+            // the halo stream: store the item requested HD steps ago (into the NEXT chunk's buffer: nobody reads it before the
+            // barrier that ends step 7 of this chunk; slot 8 is always a sink slot because R <= 512), then reuse its registers
+            // for a new request.  Items past the last chunk read the zero page and land in the sink row: no conditional
+            // request or store in the stream.
+            hstore(hv[u % HD], sc, ss);
+            if (++ss >= HT) { ss = 0; ++sc; }
+            hv[u % HD] = hload(hc, hs);
+            if (++hs >= HT) { hs = 0; ++hc; }
+        };
         auto hstep = [&](int u, bool has_next, bool do_req, bool do_store) {
+            if (late) hstores(u, do_store);
             if (!M16) {
                 fragsA(FA1, avc, 1);                            // (this step, k-half 1)
                 fragsB(FB1, u % 3, 1);
@@ -754,15 +783,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
                     avc[b2] = avn[b2];
                 }
             }
-            if (do_store) lstoreB((u + 2) % 3, rb[(u + 2) % PD]);
-            // the halo stream: store the item requested HD steps ago (into the NEXT chunk's buffer: nobody reads it before the
-            // barrier that ends step 7 of this chunk; slot 8 is always a sink slot because R <= 512), then reuse its registers
-            // for a new request.  Items past the last chunk read the zero page and land in the sink row: no conditional
-            // request or store in the stream.
-            hstore(hv[u % HD], sc, ss);
-            if (++ss >= HT) { ss = 0; ++sc; }
-            hv[u % HD] = hload(hc, hs);
-            if (++hs >= HT) { hs = 0; ++hc; }
+            if (!late) hstores(u, do_store);
             __syncthreads();
         };
         int ks = 0;

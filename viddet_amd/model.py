@@ -902,6 +902,12 @@ class YOLOV3(object):
             bufs['dz'] = torch.empty(mx, device=dev)
             bufs['dz2'] = torch.empty(mx, device=dev)
             bufs['tmp'] = torch.empty(mx, device=dev)
+        # The plan-time autotuner times candidate kernels in place on these buffers.  Fresh allocations are zero pages, and on
+        # all-zero operands the chip holds a ~20 % higher clock - for every candidate, but not equally: stand-alone the 256x128
+        # tiles on the two MFMA shapes tie at 310 TF on zeros and differ by 8 % (255 vs 275) on real data.  Tune on noise.
+        for nm, t in bufs.items():
+            if torch.is_tensor(t) and t.dtype == torch.float32 and not nm.startswith('amax'):
+                t.normal_()
         self._programs[ck] = bufs
         return bufs
 
