@@ -150,3 +150,60 @@ def test_train_script_steps_equal_the_protocol_loop(tmp_path, monkeypatch, no_wd
     assert torch.equal(net.momentum_buf, ref.momentum_buf)
     gam = net.collect_params()["stages.0.2.body.0.1.gamma"]
     assert gam.wd_mult == (0.0 if no_wd else 1.0)
+
+
+def _run_ranks(script, args, cwd, world=2, port=29561):
+    """The entry point as `world` processes (gloo, all on the one GPU: RCCL refuses two ranks on a device)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VD_DIST_BACKEND="gloo", VD_AUTOTUNE="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, script)] + args, cwd=cwd, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    return [(p.returncode, o, e) for p, (o, e) in zip(procs, outs)]
+
+
+def test_detect_script_two_ranks_write_what_one_rank_writes(tmp_path):
+    """Frames sharded over two ranks: ONE complete set of prediction files (rank 0 writes the merged detections - no rank
+    clobbers another's images with empty files) equal to the single-process files line by line, and the whole-set mAP."""
+    import detect_yolo3 as D
+    path, P = _params_file(tmp_path, 20, seed=72, obj_bias=-1.0)
+    common = ["--model_path", path, "--dataset", "voc", "--batch_size", "2", "--data_shape", "96", "--synthetic_samples", "7",
+              "--metrics", "voc"]
+    one = D.main(common + ["--save_dir", str(tmp_path / "one"), "--save_prefix", "p"])
+    res = _run_ranks("detect_yolo3.py", common + ["--save_dir", str(tmp_path / "two"), "--save_prefix", "p"], str(tmp_path))
+    assert all(rc == 0 for rc, _, _ in res), [e[-800:] for _, _, e in res]
+    a, b = tmp_path / "one" / "p" / "pred", tmp_path / "two" / "p" / "pred"
+    files = sorted(os.listdir(a))
+    assert files == sorted(os.listdir(b)) and len(files) == 7
+    nlines = 0
+    for f in files:
+        la, lb = (a / f).read_text().splitlines(), (b / f).read_text().splitlines()
+        assert len(la) == len(lb), f
+        for x, y in zip(la, lb):
+            xa, ya = x.split(","), y.split(",")
+            assert xa[:2] == ya[:2] and np.allclose([float(v) for v in xa[2:]], [float(v) for v in ya[2:]], atol=2e-6), (f, x, y)
+        nlines += len(la)
+    assert nlines > 10
+    maps = [ln for ln in res[0][1].splitlines() if ln.startswith("mAP=")]
+    assert maps and abs(float(maps[-1].split("=")[1]) - one[1][-1]) < 1e-4 and "mAP=" not in res[1][1]
+
+
+def test_train_script_two_ranks_start_train_validate(tmp_path):
+    """train_yolov3.py as two ranks: the start-up directory decision is rank 0's and reaches both (a second start on the same
+    prefix stops BOTH ranks), the step runs with SyncBN + bucketed all-reduce + global-batch rescale, and validation reports
+    the WHOLE validation set (the per-rank shards' detections are exchanged) - the same mAP on both ranks."""
+    args = ["--batch_size", "4", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "8", "--save_prefix", "dp",
+            "--log_interval", "1", "--syncbn"]
+    res = _run_ranks("train_yolov3.py", args, str(tmp_path), port=29563)
+    assert all(rc == 0 for rc, _, _ in res), [e[-1200:] for _, _, e in res]
+    log = (tmp_path / "models" / "experiments" / "dp" / "yolo3_darknet53_voc_train.log").read_text()
+    assert "End Val: # samples: 8" in log and "[Epoch 1] Validation:" in log
+    assert (tmp_path / "models" / "experiments" / "dp" / "yolo3_darknet53_voc_0001.params").exists()
+    again = _run_ranks("train_yolov3.py", args, str(tmp_path), port=29565)
+    assert all(rc != 0 for rc, _, _ in again) and all("exists so won't overwrite" in e for _, _, e in again), \
+        [(rc, e[-300:]) for rc, _, e in again]

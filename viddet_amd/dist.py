@@ -20,7 +20,8 @@ def init_from_env(backend=None):
     if world <= 1 or dist.is_initialized():
         return rank(), world_size()
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # VD_DIST_BACKEND=gloo: rehearse N ranks on ONE GPU (RCCL refuses two ranks on a device); not a measurement mode
+        backend = os.environ.get("VD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
