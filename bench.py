@@ -276,6 +276,14 @@ def main():
                 "algorithmic_gflop_per_launch": round(ig[0] / ig[2] / 1e9, 3)}
         if math is not None:
             roof["by_math"] = math
+            # not part of `frac`: what a bare f16-MFMA K loop of the kernel's shape sustains on this chip with random
+            # operands (the power limit lowers the clock as the multipliers toggle) - measured once, not live
+            if math["f16x2"]["tflops"]:
+                roof["sustained_reference"] = {
+                    "f16_mfma_tflops_random_operands": 1470.0, "f16_mfma_tflops_zero_operands": 2250.0,
+                    "fp32_equivalent_tflops": round(1470.0 / 3, 1),
+                    "f16x2_launches_frac_of_it": round(math["f16x2"]["tflops"] / (1470.0 / 3), 4),
+                    "source": "profiles/r02_mfma_ceiling.txt (tools/mfma_ceiling.hip)"}
             roof["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
         roof["algorithmic_mb_per_launch"] = round(sum(m["bytes"] for f_, m, _, _ in recs if f_ == "vd_conv_igemm") / ig[2] / 1e6, 1)
         # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this very
