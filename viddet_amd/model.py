@@ -607,8 +607,9 @@ class YOLOV3(object):
         self._recording = False
         self._programs = {}
         self._fold_dirty = True
-        self._dgrad_dirty = True
-        self._pack_stream = None
+        self._stats_version = 1          # bumped whenever the BatchNorm running statistics move
+        self._weights_version = 1        # bumped whenever the weights move; each training plan packs its own data-gradient
+        self._pack_stream = None         # weight layouts and remembers the version they were packed from
         self._pack_event = None
         self._graph_cache = {}
         self.use_graphs = False
@@ -850,8 +851,7 @@ class YOLOV3(object):
 
     def _params_changed(self):
         self._fold_dirty = True
-        self._dgrad_dirty = True
-        self._bf16_fresh = False
+        self._weights_version += 1
         self._wamax_dirty = True
 
     def _refresh_wamax(self):
@@ -1129,9 +1129,11 @@ class YOLOV3(object):
             if n.head:
                 d.flags, d.shift = EPI_AFFINE, n.bias.data_ptr()
             else:
-                sc = torch.zeros(co_p, device=dev)
-                sh = torch.zeros(co_p, device=dev)
-                n.bf_scale, n.bf_shift = sc, sh
+                # padded fp32 fold vectors: one pair per NODE, shared by the plans of every input shape (a per-plan pair
+                # would go stale in all plans but the one that last refreshed it)
+                if getattr(n, 'bf_scale', None) is None or n.bf_scale.numel() != co_p:
+                    n.bf_scale, n.bf_shift = torch.zeros(co_p, device=dev), torch.zeros(co_p, device=dev)
+                sc, sh = n.bf_scale, n.bf_shift
                 d.flags = EPI_AFFINE | EPI_LEAKY | (EPI_RESIDUAL if n.residual else 0)
                 d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
                 if n.residual:
@@ -1222,13 +1224,15 @@ class YOLOV3(object):
             if key not in self._programs:
                 built = self._build_infer_bf16(B, H, W)
                 self._refresh_bf16(built[3])
-                self._bf16_fresh = True
+                built[1]['packs_version'] = (self._weights_version, self._stats_version)
                 self._tune_bf16(built[0])
                 self._programs[key] = built
             prog, bufs, o, packs = self._programs[key]
-            if self._fold_dirty or not getattr(self, '_bf16_fresh', False):
+            # every plan owns its bf16 weight images: refreshed when the weights / running statistics moved since THIS
+            # plan last packed them (a net-wide flag would leave the other shapes' plans stale)
+            if bufs.get('packs_version') != (self._weights_version, self._stats_version):
                 self._refresh_bf16(packs)
-                self._bf16_fresh = True
+                bufs['packs_version'] = (self._weights_version, self._stats_version)
         else:
             key = ('infer', B, H, W)
             if key not in self._programs:
@@ -1758,7 +1762,7 @@ class YOLOV3(object):
     def _refresh_dgrad(self, tp, overlap=False):
         """Re-pack the data-gradient weight layout after the weights moved. With overlap=True (start of a training
         step) the 72 small pack launches run on a side stream beside the forward pass; backward() waits on the event."""
-        if not self._dgrad_dirty:
+        if tp.get('dgrad_version') == self._weights_version:
             return
         ev = None
         if overlap and self.overlap_wgrad:
@@ -1777,7 +1781,7 @@ class YOLOV3(object):
                 ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
                                       tap_ids=plan['tap_ids'], src_packed=True)
         self._pack_event = ev
-        self._dgrad_dirty = False
+        tp['dgrad_version'] = self._weights_version
 
     @staticmethod
     def _run_segments(segs):
@@ -1814,6 +1818,7 @@ class YOLOV3(object):
         self._refresh_dgrad(tp, overlap=True)
         self._run_segments(tp['fwd'])
         self._fold_dirty = True            # running stats moved
+        self._stats_version += 1
         self._last_train = tp
         L_ = tp['losses']
         if self.temporal_out:
