@@ -302,9 +302,10 @@ def test_data_parallel_two_ranks_equal_one_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items() if not k.startswith("VD_DP_")}
     # duplicate shards: bit-identical step; real shards: the update agrees as a whole; then the BASELINE configs[3] family -
-    # k = 3 windows with the SyncBN scope the reference's --syncbn reaches (stem + stride-2 convs), duplicate shards
+    # k = 3 windows with the SyncBN scope the reference's --syncbn reaches (stem + stride-2 convs), duplicate shards; and
+    # three consecutive steps (momentum, the repacked weight layouts and max-abs slots after each update), bit-identical
     for extra in (dict(VD_DP_DUP="1"), dict(), dict(VD_DP_DUP="1", VD_DP_K="3", VD_DP_SCOPE="reference"),
-                  dict(VD_DP_K="3")):
+                  dict(VD_DP_K="3"), dict(VD_DP_DUP="1", VD_DP_STEPS="3")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
                            text=True, timeout=600, env=dict(base, **extra))
         assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (extra, r.stdout[-800:], r.stderr[-1500:])

@@ -22,6 +22,7 @@ os.environ.setdefault("VD_AUTOTUNE", "0")
 C, SIZE, PER_RANK = 4, 64, 2
 K = int(os.environ.get("VD_DP_K", "1"))                 # frames per window: 3 = the BASELINE configs[3] family (YOLOV3T, late max join)
 SCOPE = os.environ.get("VD_DP_SCOPE", "all")            # SyncBN scope: 'all', or 'reference' = the six layers --syncbn reaches
+STEPS = int(os.environ.get("VD_DP_STEPS", "1"))         # optimiser steps on the same batch (> 1: the repacks after a step, under DP)
 
 
 def make(world):
@@ -36,10 +37,11 @@ def make(world):
 
 def one_step(net, x, gt, tg, global_batch):
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    out = net(dv(x), dv(gt), *[dv(t) for t in tg])
-    net.backward()
-    net.allreduce_grads()
-    net.sgd_step(0.01, 0.9, 5e-4, batch_size=global_batch)
+    for _ in range(STEPS):
+        out = net(dv(x), dv(gt), *[dv(t) for t in tg])
+        net.backward()
+        net.allreduce_grads()
+        net.sgd_step(0.001 if STEPS > 1 else 0.01, 0.9, 5e-4, batch_size=global_batch)
     torch.cuda.synchronize()
     return [o.cpu().numpy() for o in out]
 
