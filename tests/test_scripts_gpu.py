@@ -80,8 +80,12 @@ def test_train_script_default_path(tmp_path, monkeypatch):
     """BASELINE configs[0]: yolo3_darknet53_voc, batch_size 4, 416x416 through train_yolov3.py's default flags."""
     import train_yolov3 as T
     monkeypatch.chdir(tmp_path)
+    # default flags = the reference's random-shape training (a side of 320 ... 608 drawn every `interval` batches; 1 here, so
+    # that the two iterations of this run draw twice) and validation at --data_shape
     net = T.main(["--batch_size", "4", "--data_shape", "416", "--epochs", "1", "--synthetic_samples", "8",
-                  "--save_prefix", "0000", "--log_interval", "1"])
+                  "--save_prefix", "0000", "--log_interval", "1", "--random_shape_interval", "1"])
+    shapes = sorted(k[2] for k in net._programs if k[0] == 'train')
+    assert shapes and all(s_ % 32 == 0 and 320 <= s_ <= 608 for s_ in shapes), shapes
     pre = tmp_path / "models" / "experiments" / "0000"
     log = (pre / "yolo3_darknet53_voc_train.log").read_text()
     assert "[Epoch 0][Batch 1/2], LR: 1.00E-03" in log and "ObjLoss=" in log and "[Epoch 0] Training cost" in log
@@ -108,7 +112,7 @@ def test_train_script_default_path(tmp_path, monkeypatch):
     (tmp_path / "models" / "experiments" / "0007").mkdir(parents=True)
     with pytest.raises(SystemExit):
         T.main(["--batch_size", "4", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "4",
-                "--save_prefix", "0007"])
+                "--save_prefix", "0007", "--no_random_shape"])
 
 
 @pytest.mark.parametrize("no_wd", [False, True])
@@ -131,7 +135,7 @@ def test_train_script_steps_equal_the_protocol_loop(tmp_path, monkeypatch, no_wd
     M._TUNE_CACHE.clear()
     size, bs, seed, lr = 96, 4, 233, 0.01
     args = ["--batch_size", str(bs), "--data_shape", str(size), "--epochs", "1", "--synthetic_samples", str(bs),
-            "--save_prefix", "0000", "--val_interval", "1000", "--lr", str(lr)] + (["--no_wd"] if no_wd else [])
+            "--save_prefix", "0000", "--val_interval", "1000", "--lr", str(lr), "--no_random_shape"] + (["--no_wd"] if no_wd else [])
     net = T.main(args)
     # the batches the script saw: same dataset, transform and loader seeds (train_yolov3.py get_dataset / get_dataloader)
     ds = SyntheticDetection("voc", num_samples=bs, seed=seed)
@@ -198,7 +202,7 @@ def test_train_script_two_ranks_start_train_validate(tmp_path):
     prefix stops BOTH ranks), the step runs with SyncBN + bucketed all-reduce + global-batch rescale, and validation reports
     the WHOLE validation set (the per-rank shards' detections are exchanged) - the same mAP on both ranks."""
     args = ["--batch_size", "4", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "8", "--save_prefix", "dp",
-            "--log_interval", "1", "--syncbn"]
+            "--log_interval", "1", "--syncbn", "--no_random_shape"]
     res = _run_ranks("train_yolov3.py", args, str(tmp_path), port=29563)
     assert all(rc == 0 for rc, _, _ in res), [e[-1200:] for _, _, e in res]
     log = (tmp_path / "models" / "experiments" / "dp" / "yolo3_darknet53_voc_train.log").read_text()

@@ -175,3 +175,26 @@ def test_inference_transform_uint8_and_float_paths_agree():
     std = np.array([0.229, 0.224, 0.225], np.float32)
     assert np.array_equal(xf, np.ascontiguousarray(((xu.astype(np.float32) / 255.0 - MEAN) / std).transpose(2, 0, 1)))
     assert np.array_equal(xu, V.imresize(img, 64, 64, interp=9))                       # transforms.py:332 interp = 9
+
+
+def test_random_shape_loader_draws_one_shape_per_interval_and_the_same_on_every_rank():
+    """train_yolov3.py:262-271 (gluoncv RandomTransformDataLoader, the reference's default training loader): a transform
+    out of the list every `interval` batches, a whole batch through one of them; every rank of a data-parallel run draws
+    the same sequence (its shards belong to one global batch)."""
+    from viddet_amd.data import Loader
+    ds = SyntheticDetection("voc", num_samples=24, size=(120, 90))
+    mk = lambda seed: [YOLO3VideoTrainTransform(s, s, 20, V.Rng.seeded(seed)) for s in (32, 64, 96)]
+    seqs = []
+    for rank in (0, 1):
+        ld = Loader(ds, mk(5 + rank), 2, train=True, shuffle=True, seed=5, rank=rank, world=2, interval=2)
+        shapes = []
+        for batch in ld:
+            assert batch[0].shape[0] == 2 and batch[0].shape[2] == batch[0].shape[3]
+            shapes.append(batch[0].shape[-1])
+            g = batch[0].shape[-1] // 32
+            assert batch[1].shape[1] == 3 * (g * g + 4 * g * g + 16 * g * g)          # targets of that shape's grids
+        assert len(shapes) == 6 and all(shapes[i] == shapes[i - 1] for i in range(1, 6, 2)), shapes
+        seqs.append(shapes)
+    assert seqs[0] == seqs[1] and len(set(seqs[0])) > 1, seqs
+    with pytest.raises(ValueError):
+        Loader(ds, mk(0), 2, train=False)

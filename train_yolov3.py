@@ -75,6 +75,8 @@ def parse_flags(argv=None):
     A("--syncbn_scope", default="all", choices=["all", "reference"],
       help="'reference' = only the stem and stride-2 convs, which is all the reference's --syncbn reaches")
     A("--no_random_shape", type=_bool, nargs="?", const=True, default=False)
+    A("--random_shape_interval", type=int, default=10,
+      help="batches between two draws of the training shape (the reference hard-codes interval=10, train_yolov3.py:270)")
     A("--no_wd", type=_bool, nargs="?", const=True, default=False)
     A("--mixup", type=_bool, nargs="?", const=True, default=False)
     A("--no_mixup_epochs", type=int, default=20)
@@ -138,9 +140,13 @@ def get_dataloader(train_dataset, val_dataset, data_shape, batch_size, rank, wor
         val_loader = Loader(val_dataset, YOLO3NBVideoInferenceTransform(w, h), per_rank, train=False,
                             last_batch="discard", rank=rank, world=world)
         return train_loader, val_loader
-    train_loader = Loader(train_dataset, YOLO3VideoTrainTransform(w, h, train_dataset.num_class,
-                                                                   Rng.seeded(FLAGS.seed + rank)),
-                          per_rank, train=True, shuffle=True, seed=FLAGS.seed, rank=rank, world=world)
+    rng = Rng.seeded(FLAGS.seed + rank)
+    if FLAGS.no_random_shape:                          # :258-262
+        tf = YOLO3VideoTrainTransform(w, h, train_dataset.num_class, rng)
+    else:                                              # :263-271 the default: a random side of 320 ... 608 every 10 batches
+        tf = [YOLO3VideoTrainTransform(x * 32, x * 32, train_dataset.num_class, rng) for x in range(10, 20)]
+    train_loader = Loader(train_dataset, tf, per_rank, train=True, shuffle=True, seed=FLAGS.seed, rank=rank, world=world,
+                          interval=FLAGS.random_shape_interval)
     # validation frames travel as uint8 and are normalised on the device (same arithmetic, a quarter of the bytes)
     val_loader = Loader(val_dataset, YOLO3VideoInferenceTransform(w, h, device_normalize=True), per_rank, train=False,
                         last_batch="keep", rank=rank, world=world)

@@ -213,13 +213,28 @@ def pad_stack(arrs, pad_val=-1.0):
 
 
 class Loader:
-    """Minimal single-process loader (the reference's multi-worker DataLoader only feeds the host pipeline)."""
+    """Minimal single-process loader (the reference's multi-worker DataLoader only feeds the host pipeline).
+
+    `transform` may be a LIST of transforms: then this is gluoncv's RandomTransformDataLoader (train_yolov3.py:262-271, the
+    reference's DEFAULT training loader: YOLO3VideoTrainTransform at 320, 352, ... 608 pixels) - one of them is drawn
+    when iteration starts and again every `interval` batches, and a whole batch goes through the same one (so a batch
+    has one shape).  The draw comes from a generator seeded with `seed` alone, the same on every rank: under data
+    parallelism all shards of a global batch must have one shape, as the reference's single split_and_load batch does.
+    [UPSTREAM-UNVERIFIED] gluoncv draws with numpy's global generator from its worker-feeding thread, interleaved with
+    the workers' own draws, so the reference's sequence of shapes is not reproducible either."""
 
     def __init__(self, dataset, transform, batch_size, train, shuffle=False, last_batch="rollover", seed=0,
-                 rank=0, world=1):
+                 rank=0, world=1, interval=10):
         self.ds, self.tf, self.bs, self.train = dataset, transform, batch_size, train
         self.shuffle, self.last_batch, self._rng = shuffle, last_batch, np.random.default_rng(seed)
         self.rank, self.world = rank, world
+        self.tfs = list(transform) if isinstance(transform, (list, tuple)) else None
+        self.interval = max(1, int(interval))
+        self._choice = np.random.RandomState(seed)
+        if self.tfs is not None:
+            if not self.tfs or not train:
+                raise ValueError("a list of transforms is the training-time random-shape loader")
+            self.tf = self.tfs[0]
 
     def __len__(self):
         if self.last_batch == "keep":                    # every sample of this rank's shard (validation / detection)
@@ -234,6 +249,8 @@ class Loader:
         idx = idx[self.rank::self.world]                 # frames are sharded across ranks, windows never split
         for i in range(len(self)):
             chunk = idx[i * self.bs:(i + 1) * self.bs]
+            if self.tfs is not None and i % self.interval == 0:
+                self.tf = self.tfs[int(self._choice.randint(len(self.tfs)))]
             if self.train:
                 # Stack every column, Pad(-1) the trailing gt boxes (train_yolov3.py:238 / :252: 8+1 columns with
                 # cached features, 6+1 with frames)

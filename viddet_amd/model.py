@@ -1222,7 +1222,11 @@ class YOLOV3(object):
         if self.precision == 'bf16':
             key = ('infer_bf16', B, H, W)
             if key not in self._programs:
-                built = self._build_infer_bf16(B, H, W)
+                try:
+                    built = self._build_infer_bf16(B, H, W)
+                except torch.cuda.OutOfMemoryError:
+                    self._drop_plans()
+                    built = self._build_infer_bf16(B, H, W)
                 self._refresh_bf16(built[3])
                 built[1]['packs_version'] = (self._weights_version, self._stats_version)
                 self._tune_bf16(built[0])
@@ -1236,7 +1240,11 @@ class YOLOV3(object):
         else:
             key = ('infer', B, H, W)
             if key not in self._programs:
-                self._programs[key] = self._build_infer(B, H, W)
+                try:
+                    self._programs[key] = self._build_infer(B, H, W)
+                except torch.cuda.OutOfMemoryError:
+                    self._drop_plans()
+                    self._programs[key] = self._build_infer(B, H, W)
             prog, bufs, o = self._programs[key]
             self._refresh_fold()
         self._stage_inputs(bufs, x)
@@ -1791,11 +1799,28 @@ class YOLOV3(object):
             else:
                 s()
 
+    def _drop_plans(self, keep=None):
+        """Forget every cached plan (programs, activation / gradient buffers, graphs) except `keep`, and return their
+        memory to the driver."""
+        for k in [k for k in self._programs if k != keep]:
+            del self._programs[k]
+        self._graph_cache.clear()
+        self._last_train = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
     def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
         B, H, W = self._in_shape(x)
         key = ('train', B, H, W)
         if key not in self._programs:
-            self._programs[key] = self._build_train(B, H, W)
+            # every input shape owns its plan and buffers (random-shape training visits ten); when the next one does not
+            # fit beside the others, drop those and build again - their kernel choices stay in the tuning cache
+            try:
+                self._programs[key] = self._build_train(B, H, W)
+            except torch.cuda.OutOfMemoryError:
+                self._drop_plans(keep=None)
+                self._programs[key] = self._build_train(B, H, W)
         tp = self._programs[key]
         f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         gt, obj, ctr, scl, wgt, cls = [f32(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
