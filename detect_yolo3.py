@@ -148,8 +148,12 @@ def main(argv=None):
     FLAGS.window = [int(s) for s in FLAGS.window]
     if FLAGS.window[0] == 1:
         FLAGS.k_join_type = FLAGS.k_join_pos = None
-    for flag in ("temp", "mult_out", "new_model", "motion_stream", "rnn_pos", "corr_pos", "visualise", "model_agnostic"):
-        if getattr(FLAGS, flag):
+    # accepted for command-line compatibility, refused when they would change the result (never silently ignored):
+    # research variants, visualisation, the VID metric's options, evaluation on another dataset's class list
+    for flag in ("temp", "mult_out", "new_model", "motion_stream", "rnn_pos", "corr_pos", "visualise", "model_agnostic",
+                 "metric_agnostic", "offset", "per_frame_metric", "worst_video_path", "trained_on"):
+        v = getattr(FLAGS, flag)
+        if v and not (isinstance(v, str) and not v.strip()):
             raise NotImplementedError("--%s is outside the yolo3_darknet53 hot path" % flag)
     rank, world = vdist.init_from_env()
     if not torch.cuda.is_available():

@@ -291,6 +291,26 @@ def test_reset_class_reuses_rows():
     ids, sc, bx = net(x)
     torch.cuda.synchronize()
     assert ids.shape == (1, 100, 1)
+    # the fine-tuning order of train_yolov3.py (--freeze_base --trained_on ...): freeze, then reset the classes - the
+    # backbone stays frozen, the rebuilt prediction convs train
+    net2, _ = _mk_net(4, 7, obj_bias=0.0)
+    for k, p in net2.collect_params().items():
+        if k.startswith("stages.") and p.span is not None:
+            p.grad_req = 'null'
+    net2.reset_class(["a", "b", "c"])
+    P2 = net2.collect_params()
+    assert P2["stages.0.0.0.weight"].grad_req == 'null' and P2["yolo_outputs.0.prediction.weight"].grad_req == 'write'
+    assert P2["yolo_blocks.0.tip.0.weight"].grad_req == 'write'
+    rng = np.random.default_rng(3)
+    x2 = rng.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    gt, tg = _targets(rng, 2, 3, 64, 3)
+    w0 = {k: p.data().clone() for k, p in P2.items()}
+    net2(dev(x2), dev(gt), *[dev(t) for t in tg])
+    net2.backward()
+    net2.sgd_step(lr=0.01, momentum=0.9, wd=5e-4, batch_size=2)
+    torch.cuda.synchronize()
+    assert torch.equal(P2["stages.2.4.body.1.0.weight"].data(), w0["stages.2.4.body.1.0.weight"])
+    assert not torch.equal(P2["yolo_outputs.1.prediction.weight"].data(), w0["yolo_outputs.1.prediction.weight"])
 
 
 def test_data_parallel_two_ranks_equal_one_process():

@@ -108,6 +108,13 @@ def test_train_script_default_path(tmp_path, monkeypatch):
         assert np.all(np.isfinite(a)), k
         moved += int(not np.array_equal(a, ref0.collect_params()[k].data().cpu().numpy()))
     assert moved == len(net.collect_params()), "every tensor (weights, gamma/beta, running statistics) moves in a step"
+    # --trained_on: built with that dataset's classes (80), prediction convs reset to the training set's (20); --mixup refused
+    net2 = T.main(["--batch_size", "2", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "2", "--save_prefix", "0000",
+                   "--trained_on", "coco", "--no_random_shape", "--val_interval", "1000"])
+    assert len(net2.classes) == 20 and net2.collect_params()["yolo_outputs.0.prediction.weight"].shape[0] == 75
+    with pytest.raises(NotImplementedError):
+        T.main(["--batch_size", "2", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "2", "--save_prefix", "0000",
+                "--mixup", "--no_random_shape"])
     # a second start on the same prefix is refused unless it is '0000' (train_yolov3.py:713-723)
     (tmp_path / "models" / "experiments" / "0007").mkdir(parents=True)
     with pytest.raises(SystemExit):

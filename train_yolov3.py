@@ -191,6 +191,12 @@ def get_net(classes, rank_world):
     for flag in ("new_model", "motion_stream", "rnn_pos", "corr_pos"):
         if getattr(FLAGS, flag):
             raise NotImplementedError("--%s selects a research variant outside the yolo3_darknet53 hot path" % flag)
+    if FLAGS.mixup:
+        # gluoncv.data.MixupDetection (absent offline) appends the mix ratio as a 7th label column, after which the
+        # reference's video transform takes columns 4..4+num_classes - class id, 'difficult' flag and the ratio - as a
+        # multi-hot class vector (transforms.py:264-267).  The target generator here takes gt_mixratio
+        # (targets.prefetch_targets), but that label path is not one to reproduce: refuse instead of ignoring the flag.
+        raise NotImplementedError("--mixup: the reference's mixup label path (gluoncv MixupDetection + transforms.py:264-267) is not built")
     k = int(FLAGS.window[0])
     if FLAGS.features_dir is not None:                 # :335-342
         net = yolo3_no_backbone(classes, norm_layer="syncbn" if FLAGS.syncbn and rank_world[1] > 1 else None,
@@ -362,7 +368,14 @@ def main(argv=None):
         os.makedirs(save_dir, exist_ok=True)
     vdist.barrier()
     save_prefix = os.path.join(save_dir, "yolo3_" + FLAGS.network + "_" + "_".join(FLAGS.dataset))
-    net, start_epoch = get_net(train_dataset.classes, (rank, world))
+    # train_yolov3.py:708-729: --trained_on builds (and --resume loads) the network with THAT dataset's classes, then the
+    # prediction convs are reset to the training set's (rows of classes present in both are kept)
+    trained_classes = train_dataset.classes
+    if FLAGS.trained_on.strip():
+        trained_classes = SyntheticDetection(FLAGS.trained_on.strip(), num_samples=1).classes
+    net, start_epoch = get_net(trained_classes, (rank, world))
+    if FLAGS.trained_on.strip():
+        net.reset_class(train_dataset.classes)
     train_data, val_data = get_dataloader(train_dataset, val_dataset, FLAGS.data_shape, FLAGS.batch_size, rank, world)
     train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, start_epoch, FLAGS.num_samples, rank, world)
     return net

@@ -778,6 +778,7 @@ class YOLOV3(object):
     def reset_class(self, classes, reuse_weights=None):
         """yolo3.py:1230-1302 + YOLOOutputV3.reset_class :76-129: rebuild the 3 prediction convs."""
         old_classes, old = self._classes, {k: p.data().cpu() for k, p in self._params.items()}
+        old_attr = {k: (p.grad_req, p.wd_mult, p.lr_mult) for k, p in self._params.items()}
         old_npred = 5 + len(old_classes)
         if isinstance(reuse_weights, (dict, list)):
             if isinstance(reuse_weights, dict):
@@ -809,6 +810,10 @@ class YOLOV3(object):
         for name, p in self._params.items():
             if "yolo_outputs" not in name:
                 p.set_data(old[name])
+                # every parameter but the rebuilt prediction convs is the same object in the reference: it keeps its
+                # grad_req ('null' under freeze_base) and multipliers
+                if p.span is not None:
+                    p.grad_req, p.wd_mult, p.lr_mult = old_attr[name]
                 continue
             new = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.07 if name.endswith('weight') else torch.zeros(p.shape)
             if reuse_weights:
