@@ -307,9 +307,10 @@ def train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, st
             num_update += 1
             cur_lr = lr_scheduler(num_update)
             net.sgd_step(cur_lr, FLAGS.momentum, FLAGS.wd, batch_size)
+            # :637-640 every step (running means since the start of training, never reset), summed on the device
+            obj_metrics.update(0, [obj_loss]); center_metrics.update(0, [center_loss])
+            scale_metrics.update(0, [scale_loss]); cls_metrics.update(0, [cls_loss])
             if FLAGS.log_interval and not (i + 1) % FLAGS.log_interval:
-                obj_metrics.update(0, [obj_loss]); center_metrics.update(0, [center_loss])
-                scale_metrics.update(0, [scale_loss]); cls_metrics.update(0, [cls_loss])
                 (n1, l1), (n2, l2) = obj_metrics.get(), center_metrics.get()
                 (n3, l3), (n4, l4) = scale_metrics.get(), cls_metrics.get()
                 logger.info("[Epoch {}][Batch {}/{}], LR: {:.2E}, Speed: {:.3f} samples/sec, {}={:.3f}, {}={:.3f}, "
@@ -348,7 +349,9 @@ def main(argv=None):
     else:
         FLAGS.k_join_type = None
         FLAGS.k_join_pos = None
-    np.random.seed(FLAGS.seed)
+    np.random.seed(FLAGS.seed)                          # gutils.random.seed (:697): numpy, python's random, the framework
+    import random as _pyrandom
+    _pyrandom.seed(FLAGS.seed)
     torch.manual_seed(FLAGS.seed)
     rank, world = vdist.init_from_env()
     if not torch.cuda.is_available():

@@ -17,15 +17,25 @@ class LossMetric:
         self.reset()
 
     def reset(self):
-        self.sum_metric, self.num_inst = 0.0, 0
+        self.sum_metric, self.num_inst, self._dev = 0.0, 0, None
 
     def update(self, _, preds):
+        """Device tensors are summed ON the device (fp32 per call like ndarray.sum, fp64 across calls) and only read in
+        get(): the training loop updates after every step, as the reference does, without a host round trip per step."""
         for p in preds if isinstance(preds, (list, tuple)) else [preds]:
+            if hasattr(p, "detach") and p.is_cuda:
+                s = p.detach().sum().double()
+                self._dev = s if self._dev is None else self._dev + s
+                self.num_inst += int(p.numel())
+                continue
             a = p.detach().cpu().numpy() if hasattr(p, "detach") else np.asarray(p)
             self.sum_metric += float(a.sum())
             self.num_inst += int(a.size)
 
     def get(self):
+        if self._dev is not None:
+            self.sum_metric += float(self._dev)
+            self._dev = None
         return self.name, (self.sum_metric / self.num_inst if self.num_inst else float("nan"))
 
 
