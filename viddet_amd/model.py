@@ -93,9 +93,16 @@ class Program:
                 rc = fn(*a, s)
                 e1.record()
                 if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
-                    meta = dict(meta or {}, split=bool(args[0]._obj.flags & L.MATH_SPLIT),
-                                bf16=bool(args[0]._obj.flags & L.MATH_BF16), f16x2=bool(args[0]._obj.flags & L.MATH_F16X2),
-                                nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO))
+                    d = args[0]._obj
+                    meta = dict(meta or {}, split=bool(d.flags & L.MATH_SPLIT), bf16=bool(d.flags & L.MATH_BF16),
+                                f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)))
+                    if fname == "vd_conv_igemm" and meta.get("bytes"):
+                        # operands the fused epilogue reads besides input / weights: the residual (or accumulated
+                        # gradient) rows, and the producer's z rows of the fused BatchNorm-backward reductions
+                        out_bytes = 4.0 * d.N * d.Hg * d.Wg * d.Co
+                        extra = (out_bytes if d.residual else 0.0) + (out_bytes if getattr(d, "bs_part", None) else 0.0)
+                        meta["bytes_epilogue_reads"] = extra
+                        meta["bytes"] = meta["bytes"] + extra
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
