@@ -552,28 +552,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
         const int64_t m0 = (int64_t)tile_m * BM;
         const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;       // == M in this geometry
         if (tid < 16) *reinterpret_cast<f32x4*>(Ah + (tid >> 3) * ABUF + ZROW * 128 + (tid & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ---- per MFMA operand row: halo row of the centre tap and the 9-bit mask of taps inside the image
         constexpr int NRB = M16 ? 2 * TM : TM;                 // operand row blocks per wave (16 or 32 rows each)
         constexpr int RBS = M16 ? 16 : 32;
-        int jbase[NRB];
+        int jbase[NRB];                                      // filled in the prologue, under the first loads' latency
         unsigned amask[NRB];
-#pragma unroll
-        for (int b = 0; b < NRB; ++b) {
-            const int il = wm * TM * 32 + b * RBS + (lane & (RBS - 1));       // output pixel within the tile
-            const int64_t m = m0 + il;
-            const unsigned mu = m < M ? (unsigned)m : 0u;
-            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
-            const int gx = (int)(mu - t * (unsigned)p.Wg);
-            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
-            const int gy = (int)(t - n_ * (unsigned)p.Hg);
-            unsigned mk = 0u;
-            for (int t2 = 0; t2 < HT; ++t2) {
-                const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2);
-                mk |= ((unsigned)(gy + dy) < (unsigned)p.Hi && (unsigned)(gx + dx) < (unsigned)p.Wi) ? (1u << t2) : 0u;
-            }
-            amask[b] = m < M ? mk : 0u;
-            jbase[b] = il + W + 1;
-        }
         const int tap_ro = tap_dy * W + tap_dx;                // lane t: halo-row offset of tap t
         // ---- halo stream: item (chunk c, slot s) = rows lrow + 64 s of chunk c's halo, one float4 per thread.  Everything
         // that depends only on the thread is hoisted: the slot's validity (9 bits), the element offset of slot 0, the LDS
@@ -694,18 +676,37 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void
             __builtin_amdgcn_s_setprio(0);
 #endif
         };
-        // ---- prologue: the whole halo of chunk 0, the first two weight tiles, and the heads of the request streams
-        {
-            f32x4 t9[HT];
+        // ---- prologue: the whole halo of chunk 0 and the first two weight tiles are requested TOGETHER, the operand-row
+        // geometry below is computed under their latency, then everything is split and stored (one exposed round trip per
+        // tile instead of three; the K-sweep's fixed cost did not move with it - 39 us vs 37 us at 512 @26 - so the
+        // launch's fixed part is cold first touches and the tail, not these round trips)
+        f32x4 t9[HT];
 #pragma unroll
-            for (int s2 = 0; s2 < HT; ++s2) t9[s2] = hload(0, s2);
+        for (int s2 = 0; s2 < HT; ++s2) t9[s2] = hload(0, s2);
+        gloadB(rb[0]);
+        gloadB(rb[1]);
+        // ---- per MFMA operand row: halo row of the centre tap and the 9-bit mask of taps inside the image
 #pragma unroll
-            for (int s2 = 0; s2 < HT; ++s2) hstore(t9[s2], 0, s2);
+        for (int b = 0; b < NRB; ++b) {
+            const int il = wm * TM * 32 + b * RBS + (lane & (RBS - 1));       // output pixel within the tile
+            const int64_t m = m0 + il;
+            const unsigned mu = m < M ? (unsigned)m : 0u;
+            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+            const int gx = (int)(mu - t * (unsigned)p.Wg);
+            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            unsigned mk = 0u;
+            for (int t2 = 0; t2 < HT; ++t2) {
+                const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2);
+                mk |= ((unsigned)(gy + dy) < (unsigned)p.Hi && (unsigned)(gx + dx) < (unsigned)p.Wi) ? (1u << t2) : 0u;
+            }
+            amask[b] = m < M ? mk : 0u;
+            jbase[b] = il + W + 1;
         }
-        gloadB(rb[0]);
+#pragma unroll
+        for (int s2 = 0; s2 < HT; ++s2) hstore(t9[s2], 0, s2);
         lstoreB(0, rb[0]);
-        gloadB(rb[0]);
-        lstoreB(1, rb[0]);
+        lstoreB(1, rb[1]);
         __syncthreads();
         constexpr int HD = 3;                                  // halo items in flight (one request and one store per K-step)
         f32x4 hv[HD];
