@@ -222,7 +222,7 @@ def main():
             net._refresh_dgrad(tp)
             for seg in tp["fwd"] + tp["bwd"]:
                 if hasattr(seg, "run_timed"):
-                    recs += seg.run_timed({"vd_conv_igemm", "vd_conv_wgrad"})
+                    recs += seg.run_timed({"vd_conv_igemm", "vd_conv_wgrad", "vd_bn_apply_leaky"})
                 else:
                     seg()
         else:
@@ -230,6 +230,16 @@ def main():
             recs = prog.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16"})
             recs = [("vd_conv_igemm", m, e0, e1) for (_, m, e0, e1) in recs]
         torch.cuda.synchronize()
+        # the stand-alone forward BatchNorm+LeakyReLU passes, and the part of them that belongs to cells whose output feeds
+        # ONE convolution only (what fusing the pass into the consumer's gather could remove)
+        bn = [(m, e0.elapsed_time(e1)) for f_, m, e0, e1 in recs if f_ == "vd_bn_apply_leaky" and m]
+        recs = [r for r in recs if r[0] != "vd_bn_apply_leaky"]
+        if bn:
+            extra["bn_apply_leaky"] = {
+                "launches": len(bn), "ms": round(sum(t for _, t in bn), 3),
+                "gb_s": round(sum(m["bytes"] for m, _ in bn) / sum(t for _, t in bn) / 1e6, 0),
+                "single_conv_consumer_launches": sum(1 for m, _ in bn if m["single_conv_consumer"]),
+                "single_conv_consumer_ms": round(sum(t for m, t in bn if m["single_conv_consumer"]), 3)}
         agg = {}
         detail = []
         for fname, meta, e0, e1 in recs:

@@ -1440,7 +1440,9 @@ class YOLOV3(object):
                 seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, *fin)
             res = bufs[n.residual].data_ptr() if n.residual else None
             seg.add('vd_bn_apply_leaky', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
-                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE, amx(n.dst))
+                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE, amx(n.dst),
+                    meta=dict(node=n.name, bytes=4.0 * M * n.cout * (3 if n.residual else 2),
+                              single_conv_consumer=n.dst in self.single_conv_consumer_tensors()))
         # loss (targets are late-bound)
         grids = self._grid(H, W)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
@@ -1810,6 +1812,23 @@ class YOLOV3(object):
                 s.run()
             else:
                 s()
+
+    def single_conv_consumer_tensors(self):
+        """Outputs of Conv+BN+LeakyReLU cells (no residual) that are read by exactly one node, a convolution: the cells whose
+        forward BatchNorm apply could move into the consumer's operand gather (bench.py reports their share)."""
+        if getattr(self, '_scc', None) is None:
+            use = {}
+            for n in self.nodes:
+                srcs = []
+                if isinstance(n, ConvNode):
+                    srcs = [(n.src, True)] + ([(n.residual, False)] if n.residual else [])
+                else:
+                    srcs = [(getattr(n, a), False) for a in ('src', 'up', 'route', 'a', 'b') if getattr(n, a, None)]
+                for t, conv in srcs:
+                    use.setdefault(t, []).append(conv)
+            self._scc = {n.dst for n in self.conv_nodes if n.bn and not n.residual and not n.stem
+                         and use.get(n.dst) == [True] and n.dst not in [r[0] for r in ROUTE_TENSORS]}
+        return self._scc
 
     def _drop_plans(self, keep=None):
         """Forget every cached plan (programs, activation / gradient buffers, graphs) except `keep`, and return their
