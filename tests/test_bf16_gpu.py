@@ -32,6 +32,13 @@ _BF16_CASES += [(12, (2, 64, 21, 19, 32, 1, 1, 0)), (12, (2, 64, 12, 12, 24, 3, 
                 (0, (2, 64, 17, 15, 64, 3, 1, 1)), (0, (2, 64, 17, 15, 256, 3, 1, 1))]
 
 
+# halo-staged loop (3x3 stride 1 on the 8-wave tiles): several 64-channel chunks, maps wider than a tile's rows and narrower,
+# frames ending inside a tile, the 76- and 152-wide maps of the 608x608 detection path; every case also with the flag that
+# forces the generic loop
+_BF16_CASES += [(t, sh) for t in (2, 3, 6, 7, 10) for sh in [(2, 192, 20, 76, 128, 3, 1, 1), (3, 128, 7, 9, 128, 3, 1, 1),
+                                                            (1, 64, 9, 152, 64, 3, 1, 1), (2, 256, 19, 19, 128, 3, 1, 1)]]
+
+
 @pytest.mark.parametrize("tile,shape", _BF16_CASES)
 def test_conv_bf16_single_layer(tile, shape):
     from viddet_amd import ops, lib as L
@@ -59,12 +66,14 @@ def test_conv_bf16_single_layer(tile, shape):
         d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo, d.ldr, d.tile = 1, ho, wo, co, 1, co, co, tile
         sc, sh = dev(scale), dev(shift)
         d.scale, d.shift, d.residual = sc.data_ptr(), sh.data_ptr(), rd.data_ptr()
-        d.flags, d.slope = 1 | 2 | 4, 0.1
-        L.check(L.load().vd_conv_igemm_bf16(C.byref(d), out_f32, L.stream_ptr()), "vd_conv_igemm_bf16")
-        torch.cuda.synchronize()
-        got = np.moveaxis(out.float().cpu().numpy(), -1, 1)
-        tol = 2e-4 if out_f32 else 2e-4 + np.abs(ref).max() * 2 ** -8      # + one bf16 rounding of the output
-        assert maxdiff(got, ref) < tol
+        for nohalo in (0, L.MATH_NOHALO):
+            d.flags, d.slope = 1 | 2 | 4 | nohalo, 0.1
+            out.zero_()
+            L.check(L.load().vd_conv_igemm_bf16(C.byref(d), out_f32, L.stream_ptr()), "vd_conv_igemm_bf16")
+            torch.cuda.synchronize()
+            got = np.moveaxis(out.float().cpu().numpy(), -1, 1)
+            tol = 2e-4 if out_f32 else 2e-4 + np.abs(ref).max() * 2 ** -8      # + one bf16 rounding of the output
+            assert maxdiff(got, ref) < tol, (nohalo, maxdiff(got, ref), tol)
 
 
 @pytest.mark.parametrize("c,b,size,obj_bias", [(4, 2, 96, -1.0),

@@ -54,9 +54,14 @@ struct RowInfoB {
 // channels - the packed weight row [T][32] is already contiguous that way, and each lane's 16-byte chunk picks its
 // tap (chunk >> 2) - so 32-channel activations are stored unpadded and a 9-tap conv takes 5 K-steps instead of 9
 // half-empty ones.
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR>
+// HALO (3x3 stride-1 'same' geometry, 8-wave tiles): the activation operand is staged once per 64-channel chunk - the tile's
+// BM output pixels plus W + 1 pixels either side, 128 B per pixel - and the nine taps read it at row offsets dy * W + dx
+// (rows of taps outside the image read a zero row): (BM + 2 W + 2) / (9 BM) of the gather bytes.  Same scheme as the fp16-split
+// halo loop of vd_conv.hip (there with the rationale and the measurements); here the stream moves bf16 rows untouched.
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR, bool HALO = false>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
                                                                   const int64_t zd_w) {
+    static_assert(!HALO || (WM * WN == 8 && !PAIR), "the halo loop exists for the 8-wave tiles");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;
@@ -217,6 +222,155 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
 
     const int nks = PAIR ? (p.T + 1) / 2 : p.T * (p.Ci / KCH);
     STAMP(1);
+    if constexpr (HALO) {
+        constexpr int HT = 9;
+        const int W = p.Wi;
+        const int R = BM + 2 * (W + 1);
+        const int ZROW = R, DROW = R + 1;                     // a zero row (taps outside the image), a sink row (idle stream slots)
+        const int ABUF = (R + 2) * ROW_B;
+        unsigned char* Ah = smem_b;                           // [2][R + 2][ROW_B]
+        unsigned char* Bh = smem_b + 2 * ABUF;                // [2][BN][ROW_B]
+        const int nchunk = p.Ci / KCH;
+        const int64_t m0 = (int64_t)tile_m * BM;
+        const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;
+        if (tid < 16) *reinterpret_cast<f32x4*>(Ah + (tid >> 3) * ABUF + ZROW * ROW_B + (tid & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        // halo stream: item (chunk c, slot s) = rows lrow + 64 s of chunk c's halo, 16 B per thread
+        unsigned hvalid = 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < HT; ++s2) {
+            const int j = lrow + 64 * s2;
+            const int64_t pin = m0 - (W + 1) + j;
+            hvalid |= (j < R && (uint64_t)pin < (uint64_t)Mtot) ? (1u << s2) : 0u;
+        }
+        const int64_t hoff0 = (m0 - (W + 1) + lrow) * (int64_t)p.Ci + lc8;
+        const int64_t hslot = 64ll * p.Ci;
+        const int hl0 = lrow * ROW_B + (tid & 7) * 16;
+        const int hsink = (DROW - lrow) * ROW_B;
+        auto hload = [&](int c, int s) -> f32x4 {
+            const bool ok = ((hvalid >> s) & 1u) && c < nchunk;
+            const int64_t sel = ok ? hoff0 + (int64_t)s * hslot + (int64_t)c * KCH : zd_in;
+            return *reinterpret_cast<const f32x4*>(in + sel);
+        };
+        auto hstore = [&](const f32x4 v, int c, int s) {
+            const int ro_ = (c & 1) * ABUF + (((hvalid >> s) & 1u) ? s * 64 * ROW_B : hsink);
+            *reinterpret_cast<f32x4*>(Ah + ro_ + hl0) = v;
+        };
+        int bt = 0, bc0 = 0;
+        auto gloadB = [&](f32x4 (&rb)[BP]) {
+            const int64_t koff = (int64_t)bt * p.Ci + bc0;
+#pragma unroll
+            for (int i = 0; i < BP; ++i) {
+                const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
+                rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
+            }
+            if (++bt >= HT) { bt = 0; bc0 += KCH; }
+        };
+        auto lstoreB = [&](int buf, const f32x4 (&rb)[BP]) {
+#pragma unroll
+            for (int i = 0; i < BP; ++i)
+                *reinterpret_cast<f32x4*>(Bh + (buf * BN + lrow + RPP * i) * ROW_B + (tid & 7) * 16) = rb[i];
+        };
+        // prologue: the whole halo of chunk 0 and the first weight tile requested together, the operand-row geometry under
+        // their latency
+        f32x4 t9[HT];
+#pragma unroll
+        for (int s2 = 0; s2 < HT; ++s2) t9[s2] = hload(0, s2);
+        gloadB(rb[0]);
+        int jbase[TM];
+        unsigned amask[TM];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int il = wm * TM * 32 + mi * 32 + (lane & 31);
+            const int64_t m = m0 + il;
+            const unsigned mu = m < M ? (unsigned)m : 0u;
+            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+            const int gx = (int)(mu - t * (unsigned)p.Wg);
+            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+            const int gy = (int)(t - n_ * (unsigned)p.Hg);
+            unsigned mk = 0u;
+            for (int t2 = 0; t2 < HT; ++t2) {
+                const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2);
+                mk |= ((unsigned)(gy + dy) < (unsigned)p.Hi && (unsigned)(gx + dx) < (unsigned)p.Wi) ? (1u << t2) : 0u;
+            }
+            amask[mi] = m < M ? mk : 0u;
+            jbase[mi] = il + W + 1;
+        }
+        const int tap_ro = tap_dy * W + tap_dx;               // lane t: halo-row offset of tap t
+#pragma unroll
+        for (int s2 = 0; s2 < HT; ++s2) hstore(t9[s2], 0, s2);
+        lstoreB(0, rb[0]);
+        __syncthreads();
+        constexpr int HD = 3;                                 // halo items in flight: one request and one store per K-step
+        f32x4 hv[HD];
+        int hc = 1, hs = 0, sc = 1, ss = 0;                   // next item to request / to store (chunk, slot)
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            hv[d] = hload(hc, hs);
+            if (++hs >= HT) { hs = 0; ++hc; }
+        }
+#pragma unroll
+        for (int d = 1; d < PD; ++d)
+            if (d < nks) gloadB(rb[d]);
+        int cc = 0, ct = 0;                                   // chunk / tap of the step being multiplied
+        auto computeH = [&](int wbuf) {
+            const int ro = __builtin_amdgcn_readlane(tap_ro, ct);
+            const unsigned char* a[TM];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int j = ((amask[mi] >> ct) & 1u) ? jbase[mi] + ro : ZROW;
+                a[mi] = Ah + (cc & 1) * ABUF + j * ROW_B + 16 * (lane >> 5);
+            }
+            const unsigned char* b = Bh + wbuf * BN * ROW_B + (wn * TN * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(a[mi] + kc * 32);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * ROW_B + kc * 32);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (++ct >= HT) { ct = 0; ++cc; }
+        };
+        auto hstream = [&](int u) {
+            // store the item requested HD steps ago into the NEXT chunk's buffer (nobody reads it before the barrier that ends
+            // this chunk's last step), then reuse its registers for a new request; items past the last chunk read the zero
+            // page and land in the sink row or in a buffer nobody reads any more: no conditional memory operation
+            hstore(hv[u % HD], sc, ss);
+            if (++ss >= HT) { ss = 0; ++sc; }
+            hv[u % HD] = hload(hc, hs);
+            if (++hs >= HT) { hs = 0; ++hc; }
+        };
+        constexpr int UNH = 6;                                // = lcm(2 weight stages, PD in {2, 3}, HD)
+        static_assert(UNH % PD == 0 && UNH % HD == 0, "unroll vs register sets");
+        int ks = 0;
+        for (; ks + UNH + PD <= nks; ks += UNH) {
+#pragma unroll
+            for (int u = 0; u < UNH; ++u) {
+                gloadB(rb[u % PD]);
+                computeH(u & 1);
+                lstoreB((u + 1) & 1, rb[(u + 1) % PD]);
+                hstream(u);
+                __syncthreads();
+            }
+        }
+        for (; ks < nks; ks += UNH) {
+#pragma unroll
+            for (int u = 0; u < UNH; ++u) {
+                if (ks + u < nks) {
+                    if (ks + u + PD < nks) gloadB(rb[u % PD]);
+                    computeH(u & 1);
+                    if (ks + u + 1 < nks) lstoreB((u + 1) & 1, rb[(u + 1) % PD]);
+                    hstream(u);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
     gload(ra[0], rb[0]);
     STAMP(2);
     lstore(0, ra[0], rb[0]);
@@ -249,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             }
         }
     }
+    }   // !HALO
 
     STAMP(4);
     // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs).  Per wave, one 32x32
@@ -388,14 +543,28 @@ const float* zero_page_b() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false>
-void launch_b(const vd_conv_desc& d, hipStream_t s) {
+// LDS bytes of the halo loop: two halo buffers of BM + 2 (W + 1) rows (+ zero row + sink row) and two weight stages
+inline int64_t halo_lds_b(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 2) * ROW_B + 2ll * BN * ROW_B; }
+
+inline bool halo_ok_b(const vd_conv_desc& d, int BM, int BN) {
+    if ((d.flags & VD_MATH_NOHALO) || d.T != 9 || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi || d.Ci % KCH)
+        return false;
+    for (int t = 0; t < 9; ++t)
+        if (d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1 || d.dz[t] != 0) return false;
+    // nine stream slots of 64 rows; the epilogue's staging patches (36 KB) reuse the same LDS
+    return BM + 2 * (d.Wi + 1) <= 9 * 64 && halo_lds_b(BM, BN, d.Wi) <= 160 * 1024;
+}
+
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false, bool HALO = false>
+void launch_b2(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int lds = 2 * (BM + BN) * ROW_B;
+    constexpr int lds_gen = 2 * (BM + BN) * ROW_B;
+    const int lds = HALO ? (int)(halo_lds_b(BM, BN, d.Wi) > 8 * 32 * 36 * 4 ? halo_lds_b(BM, BN, d.Wi) : 8 * 32 * 36 * 4) : lds_gen;
     static bool attr_done = false;
-    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR>;
+    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR, HALO>;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HALO ? 160 * 1024 : lds_gen);
         attr_done = true;
     }
     const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
@@ -404,6 +573,14 @@ void launch_b(const vd_conv_desc& d, hipStream_t s) {
     const int64_t zd_in = zp - reinterpret_cast<const __bf16*>(d.in);
     const int64_t zd_w = zp - reinterpret_cast<const __bf16*>(d.wp);
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w);
+}
+
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false>
+void launch_b(const vd_conv_desc& d, hipStream_t s) {
+    if constexpr (WM * WN == 8 && !PAIR && TM * TN <= 4) {
+        if (halo_ok_b(d, WM * TM * 32, WN * TN * 32)) return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, true>(d, s);
+    }
+    launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, false>(d, s);
 }
 
 template <bool OUT_F32>

@@ -1194,28 +1194,35 @@ class YOLOV3(object):
             if fname != 'vd_conv_igemm_bf16':
                 continue
             d, of32 = args[0]._obj, args[1]
-            key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.flags, of32)
+            base = d.flags & ~L.MATH_NOHALO
+            key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32)
             if key not in _TUNE_CACHE:
-                best, best_t = 2, None
+                best, best_t = (2, 0), None
                 verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
-                for c in ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
-                          else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ())):
-                    d.tile = c
-                    L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
-                    e1.record()
-                    e1.synchronize()
-                    t = e0.elapsed_time(e1)
-                    if verbose:
-                        fl = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
-                        print("bf16 tune %s tile %d: %.3f ms %.0f TF" % (key[1:10], c, t / 3, fl), flush=True)
-                    if best_t is None or t < best_t:
-                        best, best_t = c, t
+                tiles = ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
+                         else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()))
+                # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
+                # does not apply) is timed against the generic one
+                halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0
+                for c in tiles:
+                    for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
+                        d.tile, d.flags = c, base | fl
+                        L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
+                        e1.record()
+                        e1.synchronize()
+                        t = e0.elapsed_time(e1)
+                        if verbose:
+                            fl_ = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
+                            print("bf16 tune %s tile %d %s: %.3f ms %.0f TF" % (key[1:10], c, "generic" if fl else "halo", t / 3, fl_),
+                                  flush=True)
+                        if best_t is None or t < best_t:
+                            best, best_t = (c, fl), t
                 _TUNE_CACHE[key] = best
-            d.tile = _TUNE_CACHE[key]
+            d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
 
     # ------------------------------------------------------------------ inference
     def _in_shape(self, x):
