@@ -70,8 +70,20 @@ def _train_replication(net, x1, gt1, tg1, B, c, min_tensors, head_tol=2e-4, loss
     return outB, dev_, cos
 
 
-def test_configs2_headline_batch_64_frames_416_80_classes():
-    """BASELINE configs[2], the bench.py workload: yolo3_darknet53_coco, batch 64, 416x416, fp32."""
+@pytest.mark.parametrize("math", [None, "native", "split", "split2"])
+def test_configs2_headline_batch_64_frames_416_80_classes(math):
+    """BASELINE configs[2], the bench.py workload: yolo3_darknet53_coco, batch 64, 416x416, fp32 - under the autotuner's mix
+    (None) and with every convolution forced onto one product arithmetic (fp32 MFMA / 3-way bf16 split / 2-way fp16 split),
+    so that each family's full-size tiles run the whole network."""
+    from viddet_amd import model as M
+    M.set_conv_math(math)
+    try:
+        _headline(math)
+    finally:
+        M.set_conv_math(None)
+
+
+def _headline(math):
     c, size, B = 80, 416, 64
     net, P = _mk_net(c, 8, obj_bias=-1.0)
     rng = np.random.default_rng(8)
