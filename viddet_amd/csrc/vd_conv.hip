@@ -201,7 +201,7 @@ struct RowInfo {
 // cost 30 % of a 3x3 launch wherever they hit (L1, L2 or HBM) - the CU's load path, not the memory system, is the limit -
 // so the fix is fewer bytes INTO the CU: (BM + 2W + 2) / (9 BM) of them.
 template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3, bool HALO = false>
-__global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : 1)) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
+__global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && WM * WN == 4) ? 2 : 1))) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w) {
     static_assert(NPL == 3 || ((NPL == 1 || NPL == 2) && SP), "planes");
     static_assert(NPL != 2 || !XF, "the fp16 split needs the max-abs of the operand it splits: no in-load transform");
     static_assert(!HALO || (NPL == 2 && WM * WN == 8 && WN * TN * 32 >= 64), "the halo loop exists for the 8-wave fp16-split tiles");
@@ -1282,10 +1282,10 @@ int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
 // double-buffered 256x128 stage fill the 160 KB of LDS)
 int igemm_split_resolve_tile(const vd_conv_desc& d) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 10) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
+    if (tile <= 0 || tile > 12) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
     return tile;
 }
-int igemm_split_tile_bm(int tile) { return (tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128; }
+int igemm_split_tile_bm(int tile) { return tile >= 11 ? 128 : ((tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128); }
 
 template <bool XF>
 int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
@@ -1301,7 +1301,11 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
         case 8: return launch_igemm<4, 2, 1, 1, XF, true, true>(d, s);
         // 9, 10: 256 x 32 (8 waves of 32x32) for the 32-channel outputs of the first stage, both MFMA shapes
         case 9: return launch_igemm<8, 1, 1, 1, XF, true>(d, s);
-        default: return launch_igemm<8, 1, 1, 1, XF, true, true>(d, s);
+        case 10: return launch_igemm<8, 1, 1, 1, XF, true, true>(d, s);
+        // 11, 12: 128 x 128 as FOUR waves of 64x64 - half the LDS and threads of tile 1 at the same per-wave shape, so two
+        // workgroups share a CU and one's prologue / epilogue runs under the other's K loop (short-K 1x1 and stride-2 layers)
+        case 11: return launch_igemm<2, 2, 2, 2, XF, true>(d, s);
+        default: return launch_igemm<2, 2, 2, 2, XF, true, true>(d, s);
     }
 }
 
