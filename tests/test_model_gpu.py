@@ -352,6 +352,34 @@ def test_single_rank_rccl_path_and_exchange_diagnostics():
     assert ph["allreduce_exposed_ms"] >= 0 and ph["bwd_local_ms"] > 0 and ph["allreduce"]["algo_gb_s"] > 0
 
 
+def test_bench_two_ranks_launched_the_drivers_way():
+    """bench.py under the launcher line the driver uses for N > 1 (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...), rehearsed with two ranks sharing the
+    one GPU over gloo (VD_REHEARSE_SHARED_GPU=1; RCCL wants one device per rank): ONE JSON line from rank 0, whole-job frames/s
+    (both ranks' frames over the max-over-ranks time), the exchange diagnostics, weak scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VD_REHEARSE_SHARED_GPU="1", VD_BUCKET_MB="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "2", "--size", "64", "--classes", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert abs(out["value"] - 4 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
+    assert out["cpu_baseline"] is None and out["roofline"]["frac"] > 0
+    assert out["phases"]["allreduce"]["buckets_per_step"] >= 4 and out["phases"]["allreduce_exposed_ms"] >= 0
+
+
 @pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6)])
 def test_fp16_split_arithmetic_matches_oracle(cfg):
     """set_conv_math('split2') (VD_MATH_F16X2: two fp16 pieces per operand, per-tensor power-of-two scales from the
