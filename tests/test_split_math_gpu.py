@@ -47,7 +47,7 @@ def test_split_fwd_every_tile(tile, shape, mode):
 
 
 @pytest.mark.parametrize("mode", [True, "f16x2"])
-@pytest.mark.parametrize("tile", [9, 10])
+@pytest.mark.parametrize("tile", [9, 10, 13, 14])
 @pytest.mark.parametrize("shape", [(2, 64, 23, 19, 32, 1, 1, 0), (3, 64, 17, 15, 32, 3, 1, 1), (2, 96, 20, 22, 24, 3, 2, 1),
                                    (5, 32, 9, 31, 32, 3, 1, 1)])
 def test_split_fwd_32_column_tiles(tile, shape, mode):

@@ -1282,10 +1282,10 @@ int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
 // double-buffered 256x128 stage fill the 160 KB of LDS)
 int igemm_split_resolve_tile(const vd_conv_desc& d) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 12) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
+    if (tile <= 0 || tile > 14) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
     return tile;
 }
-int igemm_split_tile_bm(int tile) { return tile >= 11 ? 128 : ((tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128); }
+int igemm_split_tile_bm(int tile) { return tile >= 13 ? 256 : (tile >= 11 ? 128 : ((tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128)); }
 
 template <bool XF>
 int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
@@ -1305,7 +1305,11 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
         // 11, 12: 128 x 128 as FOUR waves of 64x64 - half the LDS and threads of tile 1 at the same per-wave shape, so two
         // workgroups share a CU and one's prologue / epilogue runs under the other's K loop (short-K 1x1 and stride-2 layers)
         case 11: return launch_igemm<2, 2, 2, 2, XF, true>(d, s);
-        default: return launch_igemm<2, 2, 2, 2, XF, true, true>(d, s);
+        case 12: return launch_igemm<2, 2, 2, 2, XF, true, true>(d, s);
+        // 13, 14: 256 x 32 as four waves of 64x32 (two workgroups per CU): twice the MFMAs per wave, K-step and barrier of
+        // tiles 9 / 10 for the 32-channel outputs of the first stage
+        case 13: return launch_igemm<4, 1, 2, 1, XF, true>(d, s);
+        default: return launch_igemm<4, 1, 2, 1, XF, true, true>(d, s);
     }
 }
 

@@ -164,7 +164,7 @@ def _tile_candidates(d, math):
         fls.append(L.MATH_F16X2 | L.MATH_NOHALO)
     for fl in dict.fromkeys(fls):
         if d.Co <= 32:           # 256 x 32 tiles (9: 32x32x16 MFMA, 10: 16x16x32)
-            cands += [(fl, t) for t in (9, 10)]
+            cands += [(fl, t) for t in (9, 10, 13, 14)]
         elif d.Co <= 64:         # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
             cands += [(fl, t) for t in (3, 4, 7, 8)]
         else:
