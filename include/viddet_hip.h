@@ -102,7 +102,7 @@ typedef struct {
     const float* in_scale;
     const float* in_shift;
     float   in_slope;
-    int32_t tile;           /* 0 = library heuristic; 1..10 = explicit tile variant (host autotuner) */
+    int32_t tile;           /* 0 = library heuristic; 1..8 (fp32 MFMA) / 1..16 (split arithmetics) = explicit tile variant (host autotuner) */
     /* fused BatchNorm statistics (training forward, flags must be 0): per-M-tile partial sums
      * stats_part[tile_m][0..Co) = sum, [Co..2Co) = sum of squares; vd_conv_igemm_mtiles() rows;
      * finish with vd_bn_sum_partials().  NULL = off. */

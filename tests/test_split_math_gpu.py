@@ -26,7 +26,7 @@ SHAPES = [  # n, ci, h, w, co, k, stride, pad
 
 
 @pytest.mark.parametrize("mode", [True, "f16x2", "f16x2nh"])      # f16x2: halo-staged loop on the 3x3 stride-1 shapes
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12])      # 5..8: the same tiles on the 16x16x32 MFMA shape; 11, 12: 128x128 as four waves, both shapes
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 15, 16])      # 5..8: the same tiles on the 16x16x32 MFMA shape; 11, 12: 128x128 as four waves, both shapes
 @pytest.mark.parametrize("shape", SHAPES)
 def test_split_fwd_every_tile(tile, shape, mode):
     from viddet_amd import ops
@@ -265,7 +265,7 @@ def test_split_fused_bn_statistics(math):
     ref = R.conv2d(x, wt, 1, 1)
     M = n * h * w
     fl = {"split": L.MATH_SPLIT, "f16x2": L.MATH_F16X2, "f16x2nh": L.MATH_F16X2 | L.MATH_NOHALO}[math]
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 15, 16):
         d = L.ConvDesc()
         xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
         ax, aw = ops.amax(xd), ops.amax(wp)
@@ -281,7 +281,7 @@ def test_split_fused_bn_statistics(math):
         L.check(lib.vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
         mt = lib.vd_conv_igemm_mtiles(C.byref(d))
         torch.cuda.synchronize()
-        assert mt == -(-M // (256 if tile in (1, 3, 5, 7) else 128))
+        assert mt == -(-M // (256 if tile in (1, 3, 5, 7, 15, 16) else 128))
         s1 = part[:mt, :co].double().sum(0).cpu().numpy()
         s2 = part[:mt, co:].double().sum(0).cpu().numpy()
         assert np.abs(s1 - ref.sum((0, 2, 3))).max() < 2e-3

@@ -1282,10 +1282,10 @@ int igemm_tile_bm(int tile) { return (tile == 4 || tile == 5) ? 64 : 128; }
 // double-buffered 256x128 stage fill the 160 KB of LDS)
 int igemm_split_resolve_tile(const vd_conv_desc& d) {
     int tile = d.tile;
-    if (tile <= 0 || tile > 14) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
+    if (tile <= 0 || tile > 16) tile = d.Co <= 32 ? 9 : (d.Co <= 64 ? 3 : 1);
     return tile;
 }
-int igemm_split_tile_bm(int tile) { return tile >= 13 ? 256 : (tile >= 11 ? 128 : ((tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128)); }
+int igemm_split_tile_bm(int tile) { return (tile >= 13 ? 256 : (tile >= 11 ? 128 : ((tile >= 9 || ((tile - 1) & 3) == 0 || ((tile - 1) & 3) == 2) ? 256 : 128))); }
 
 template <bool XF>
 int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
@@ -1309,7 +1309,10 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
         // 13, 14: 256 x 32 as four waves of 64x32 (two workgroups per CU): twice the MFMAs per wave, K-step and barrier of
         // tiles 9 / 10 for the 32-channel outputs of the first stage
         case 13: return launch_igemm<4, 1, 2, 1, XF, true>(d, s);
-        default: return launch_igemm<4, 1, 2, 1, XF, true, true>(d, s);
+        case 14: return launch_igemm<4, 1, 2, 1, XF, true, true>(d, s);
+        // 15, 16: 256 x 64 as four waves of 64x64 (the 128 x 64 four-wave form measured no better than tiles 4 / 8)
+        case 15: return launch_igemm<4, 1, 2, 2, XF, true>(d, s);
+        default: return launch_igemm<4, 1, 2, 2, XF, true, true>(d, s);
     }
 }
 

@@ -166,7 +166,7 @@ def _tile_candidates(d, math):
         if d.Co <= 32:           # 256 x 32 tiles (9: 32x32x16 MFMA, 10: 16x16x32)
             cands += [(fl, t) for t in (9, 10, 13, 14)]
         elif d.Co <= 64:         # split tiles 1..4 on the 32x32x16 MFMA, 5..8 the same tiles on 16x16x32
-            cands += [(fl, t) for t in (3, 4, 7, 8)]
+            cands += [(fl, t) for t in (3, 4, 7, 8)] + ([(fl, t) for t in (15, 16)] if not (fl & L.MATH_F16X2 and not fl & L.MATH_NOHALO and d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi) else [])
         else:
             # 11, 12: 128x128 as four waves (two workgroups per CU); never the halo loop, so only with the generic bit
             cands += [(fl, t) for t in (1, 2, 3, 4, 5, 6, 7, 8)] + ([(fl, t) for t in (11, 12)] if not (fl & L.MATH_F16X2 and not fl & L.MATH_NOHALO and d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi) else [])
