@@ -1861,9 +1861,9 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
     VD_REQUIRE(!d->stats_part || (d->flags & 7) == 0, "vd_conv_igemm: fused BN statistics need a raw (epilogue-free) output");
-    VD_REQUIRE(!d->bs_part || (!d->stats_part && !d->in_scale && d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd &&
-                               d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg),
-               "vd_conv_igemm: fused BN backward reductions need direct output geometry and all five bs_* inputs");
+    // (any output geometry: a stride-2 data gradient is four parity launches, each adding its own rows to the partial table)
+    VD_REQUIRE(!d->bs_part || (!d->stats_part && !d->in_scale && d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd),
+               "vd_conv_igemm: fused BN backward reductions need all five bs_* inputs (and no forward statistics / in-load transform)");
     VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || (d->amax_in && d->amax_w && !d->in_scale),
                "vd_conv_igemm: VD_MATH_F16X2 needs amax_in and amax_w (and no in-load transform)");
     hipStream_t s = (hipStream_t)stream;

@@ -112,6 +112,7 @@ class Program:
 
 
 _TUNE_CACHE = {}
+_FUSE_BWD_S2 = __import__('os').environ.get('VD_FUSE_BWD_S2', '1') == '1'   # A/B switch: fused BN-backward reductions in stride-2 data gradients
 
 
 def fp32_math():
@@ -1358,7 +1359,8 @@ class YOLOV3(object):
         smax = 16
         for n in self.conv_nodes:
             if n.bn:
-                smax = max(smax, ((B * n.fr * (H // n.div_out) * (W // n.div_out) + 63) // 64) * 2 * n.cout)
+                # (+ 8 rows: the four parity launches of a stride-2 data gradient round their tile counts up separately)
+                smax = max(smax, ((B * n.fr * (H // n.div_out) * (W // n.div_out) + 63) // 64 + 8) * 2 * n.cout)
         stats_ws = torch.empty(smax, device=dev)
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
@@ -1724,9 +1726,12 @@ class YOLOV3(object):
             res_src = alias.pop(n.src) if n.src in alias else dsrc      # the skip gradient, still living in the block's dy
             plans = dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, n.kd, n.pad_d)
             pm = producers.get(n.src)
-            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and len(plans) == 1 and n.stride == 1 and
+            # the producer's BatchNorm-backward reductions ride in this data gradient's epilogue when it is the launch (or, for a
+            # stride-2 conv, the four parity launches) that completes dy of the producer's output
+            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _FUSE_BWD_S2)) and
                             consumers[n.src][0] is n and pm.fr == n.fr) else None
-            for plan in plans:
+            bs_rows = 0
+            for pi, plan in enumerate(plans):
                 assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
                 wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
                 dgrad_packs.append((n, plan, wpk))
@@ -1749,15 +1754,16 @@ class YOLOV3(object):
                     d.bs_z = bufs['z:' + fuse_m.dst].data_ptr()
                     d.bs_scale, d.bs_shift = fuse_m.b_scale.data_ptr(), fuse_m.b_shift.data_ptr()
                     d.bs_mean, d.bs_invstd = fuse_m.b_mean.data_ptr(), fuse_m.b_invstd.data_ptr()
-                    d.bs_part, d.bs_slope = stats_ws.data_ptr(), LEAKY_SLOPE
+                    d.bs_part, d.bs_slope = stats_ws.data_ptr() + bs_rows * 2 * fuse_m.cout * 4, LEAKY_SLOPE
                     autotune_desc(d)                               # fixes the tile, hence the number of M tiles
-                    mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
+                    bs_rows += L.load().vd_conv_igemm_mtiles(C.byref(d))
+                    mt = bs_rows
                     assert mt * 2 * fuse_m.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
                     bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans))
-                if fuse_m is not None:
+                if fuse_m is not None and pi == len(plans) - 1:
                     seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
                             fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
                     fused_bwd.add(fuse_m.name)
