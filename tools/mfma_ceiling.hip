@@ -127,6 +127,7 @@ static double run(const char* name, const f16x8* src, float* out, int blocks, in
     const double tf = mf / (ms * 1e-3) / 1e12;
     printf("%-9s %-6s blocks %5d steps %5d  %8.3f ms  %7.1f TF fp16-MFMA  = %6.1f TF fp32-equivalent (3 products)  = %4.1f %% of 2500\n",
            name, data, blocks, steps, ms, tf, tf / 3, 100 * tf / 2500);
+    fflush(stdout);
     return tf;
 }
 
