@@ -1311,6 +1311,9 @@ int dispatch_igemm_split(const vd_conv_desc& d, hipStream_t s) {
         case 13: return launch_igemm<4, 1, 2, 1, XF, true>(d, s);
         case 14: return launch_igemm<4, 1, 2, 1, XF, true, true>(d, s);
         // 15, 16: 256 x 64 as four waves of 64x64 (the 128 x 64 four-wave form measured no better than tiles 4 / 8)
+        // (256 x 128 as four waves of 128x64 - one wave per SIMD, 24 LDS operand reads per 48 MFMAs instead of 16 per 24 - was
+        // measured too: 210 TF against 219 for tile 1's generic loop at 256->512 @26; fewer LDS reads do not pay for losing the
+        // second wave of a SIMD)
         case 15: return launch_igemm<4, 1, 2, 2, XF, true>(d, s);
         default: return launch_igemm<4, 1, 2, 2, XF, true, true>(d, s);
     }
