@@ -331,9 +331,10 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (("temporal-YOLO (k=%d frame windows) training, %d windows/GPU, %dx%d, fp32, fwd+bwd+"
                                      "SGD-momentum (BASELINE configs[3] family)" % (K, B, S, S)) if (train and K > 1) else
-                                    ("yolo3_darknet53_coco training, batch %d/GPU, %dx%d, bf16 conv products on fp32 tensors "
-                                     "(fp32 accumulate / BN / loss / SGD), fwd+bwd+SGD-momentum (BASELINE configs[4] "
-                                     "arithmetic on the configs[2] shape)" % (B, S, S)) if a.dtype == "bf16" else
+                                    ("yolo3_darknet53 training, %d classes, batch %d/GPU, %dx%d, bf16 conv products on fp32 tensors "
+                                     "(fp32 accumulate / BN / loss / SGD), fwd+bwd+SGD-momentum (BASELINE configs[4] arithmetic%s)"
+                                     % (C, B, S, S, "; its per-GPU shape" if (C == 285 and S == 608 and B == 32) else
+                                        " on the configs[2] shape" if (C == 80 and S == 416) else "")) if a.dtype == "bf16" else
                                     "yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
                                     "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),
