@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from viddet_amd import dist as vdist
-from viddet_amd.data import SyntheticDetection, YOLO3VideoInferenceTransform, Loader
+from viddet_amd.data import SyntheticDetection, SyntheticCombined, YOLO3VideoInferenceTransform, Loader
 from viddet_amd.metrics import VOCMApMetric
 from viddet_amd.hierarchy import ClassTree, get_class_map, hierarchical_nms, iou  # noqa: F401  (detect_yolo3.py:698-789)
 from viddet_amd.model import yolo3_darknet53
@@ -69,6 +69,7 @@ def parse_flags(argv=None):
     A("--offset", type=int, default=0)
     A("--hier_level", type=int, default=10)
     A("--synthetic_samples", type=int, default=32)
+    A("--synthetic_classes", type=int, default=None, help="classes per dataset of the synthetic combined set (default: the datasets' own counts)")
     A("--random_init", type=_bool, nargs="?", const=True, default=False,
       help="skip load_parameters (no checkpoint available offline)")
     return ap.parse_args(argv)
@@ -160,7 +161,10 @@ def main(argv=None):
         raise SystemExit("detect_yolo3.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     name = FLAGS.dataset[0]
-    dataset = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples)
+    if len(FLAGS.dataset) > 1:          # detect_yolo3.py:166-167: several datasets = the combined set with its class tree
+        dataset = SyntheticCombined(FLAGS.dataset, num_samples=FLAGS.synthetic_samples, classes_per_set=FLAGS.synthetic_classes)
+    else:
+        dataset = SyntheticDetection(name, num_samples=FLAGS.synthetic_samples)
     # frames travel as uint8 and are normalised on the device (vd_preprocess_u8_nchw: the transform's own arithmetic)
     loader = Loader(dataset, YOLO3VideoInferenceTransform(FLAGS.data_shape, FLAGS.data_shape, device_normalize=True),
                     FLAGS.batch_size, train=False, last_batch="keep", rank=rank, world=world)
@@ -186,7 +190,7 @@ def main(argv=None):
     save_predictions(save_dir, dataset, boxes, max_do=FLAGS.max_do)
     if "voc" in FLAGS.metrics:
         preds = load_predictions(save_dir, dataset, FLAGS.max_do)
-        if hasattr(dataset, "parents") and hasattr(dataset, "wn_classes"):     # detect_yolo3.py:898-899 (class-tree sets)
+        if len(FLAGS.dataset) > 1:                                              # detect_yolo3.py:898-899 (class-tree sets)
             preds = hierarchical_nms(preds, dataset, level_thresh=FLAGS.hier_level)
         (names, values), = evaluate([VOCMApMetric(iou_thresh=0.5, class_names=dataset.classes)], dataset, preds,
                                     FLAGS.data_shape)

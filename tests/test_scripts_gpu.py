@@ -76,6 +76,41 @@ def test_detect_script_writes_the_oracles_rows(tmp_path, capsys):
     assert "mAP=" in capsys.readouterr().out
 
 
+def test_detect_script_combined_set_runs_the_hierarchical_nms(tmp_path):
+    """Several --dataset names = the combined set with its class tree (detect_yolo3.py:166-167): the saved detections go
+    through hierarchical_nms (:898-899) before they are scored.  The script's mAP must equal the one computed here from
+    the files it wrote, the line-by-line oracle of the hierarchical NMS and the oracle metric."""
+    import detect_yolo3 as D
+    from oracle import hierarchy as OH
+    from viddet_amd.data import SyntheticCombined, YOLO3VideoInferenceTransform
+    size, nsamp, per = 96, 6, 3
+    ds = SyntheticCombined(["voc", "coco"], num_samples=nsamp, classes_per_set=per)
+    c = ds.num_class
+    assert c == 2 + 2 * per and ds.get_levels() == [1, 1] + [2] * (2 * per) and ds.on_branch(0, 2) and not ds.on_branch(1, 2)
+    assert all(int(l) >= 2 for i in range(nsamp) for l in ds[i][1][:, 4])
+    path, P = _params_file(tmp_path, c, seed=72, obj_bias=0.0)
+    out = D.main(["--model_path", path, "--dataset", "voc,coco", "--synthetic_classes", str(per), "--batch_size", "4",
+                  "--data_shape", str(size), "--synthetic_samples", str(nsamp), "--save_dir", str(tmp_path / "results"),
+                  "--save_prefix", "tc", "--metrics", "voc", "--hier_level", "1"])
+    preds = D.load_predictions(str(tmp_path / "results" / "tc" / "pred"), ds)
+    assert sum(len(v) for v in preds.values()) > 10
+    tree = OH.Tree(ds.classes, ds.parents)
+    ref = OH.hierarchical_nms(preds, tree, level_thresh=1)
+    # with level_thresh = 1 every leaf detection is lifted to its dataset's group label and overlapping boxes of one group merge
+    assert all(b[0] in (0, 1) for v in ref.values() for b in v) and sum(len(v) for v in ref.values()) < sum(len(v) for v in preds.values())
+    metric = Y.VOCMApMetric(iou_thresh=0.5, class_names=ds.classes)
+    tf = YOLO3VideoInferenceTransform(size, size)
+    for idx in range(nsamp):
+        img, label = ds[idx]
+        _, gt, _ = tf(img, label, idx)
+        pred = np.asarray(ref.get(ds.sample_path(idx), np.zeros((0, 6))), dtype=np.float64).reshape(-1, 6)
+        metric.update([pred[:, 2:6]], [pred[:, 0]], [pred[:, 1]], [gt[:, :4] / size], [gt[:, 4]], [gt[:, 5]])
+    aps_r, map_r = metric.get()
+    names, values = out
+    assert len(values) == c + 1 and np.allclose(values[:-1], aps_r, atol=1e-6, equal_nan=True)
+    assert (np.isnan(values[-1]) and np.isnan(map_r)) or abs(values[-1] - map_r) < 1e-6
+
+
 def test_train_script_default_path(tmp_path, monkeypatch):
     """BASELINE configs[0]: yolo3_darknet53_voc, batch_size 4, 416x416 through train_yolov3.py's default flags."""
     import train_yolov3 as T

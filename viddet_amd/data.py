@@ -60,6 +60,38 @@ class SyntheticDetection:
         return imgs, frames[self._window // 2][1]
 
 
+class SyntheticCombined(SyntheticDetection):
+    """Stand-in for CombinedDetection(datasets, class_tree=True) (detect_yolo3.py:167, datasets/combined.py): the label set of
+    several datasets arranged in a class tree - one group label per dataset under 'ROOT' (labels are ordered parents first,
+    as combined.py's tree walk orders them), that dataset's classes below it - with the attributes the hierarchical NMS
+    reads (`parents`, `wn_classes`, `get_levels()`, `on_branch()`).  Ground-truth boxes carry leaf labels."""
+
+    def __init__(self, names, num_samples=64, classes_per_set=None, **kw):
+        from .hierarchy import ClassTree, ROOT
+        per = [NUM_CLASSES.get(n, 20) if classes_per_set is None else int(classes_per_set) for n in names]
+        groups = ["grp_%s" % n for n in names]
+        leaves = ["%s_c%d" % (n, i) for n, k in zip(names, per) for i in range(k)]
+        parents = {g: ROOT for g in groups}
+        for n, k in zip(names, per):
+            parents.update({"%s_c%d" % (n, i): "grp_%s" % n for i in range(k)})
+        super().__init__("comb", num_samples=num_samples, num_class=len(groups) + len(leaves), **kw)
+        self.classes = groups + leaves
+        self.tree = ClassTree(self.classes, parents)
+        self.parents, self.wn_classes = self.tree.parents, self.tree.wn_classes
+        self._first_leaf = len(groups)
+
+    def get_levels(self):
+        return self.tree.get_levels()
+
+    def on_branch(self, c1, c2):
+        return self.tree.on_branch(c1, c2)
+
+    def _frame(self, rng):
+        img, lab = super()._frame(rng)
+        lab[:, 4] = self._first_leaf + np.mod(lab[:, 4], self.num_class - self._first_leaf)     # leaves only
+        return img, lab
+
+
 def _to_tensor_normalize(img):
     x = img.astype(np.float32) / 255.0            # mx.nd.image.to_tensor (any input dtype is divided by 255)
     x = (x - MEAN) / STD                          # mx.nd.image.normalize
