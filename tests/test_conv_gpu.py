@@ -168,6 +168,45 @@ def test_conv_wgrad(case):
     assert maxdiff(dw.cpu().numpy(), dw_ref) < TOL * scale
 
 
+XF_CASES = [(2, 64, 13, 11, 128, 3, 1, 1), (3, 32, 9, 12, 64, 1, 1, 0), (2, 64, 14, 15, 96, 3, 2, 1), (2, 128, 8, 8, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("mode", [False, True], ids=["fp32-mfma", "bf16x3"])
+@pytest.mark.parametrize("case", XF_CASES)
+def test_in_load_transform_forward_and_wgrad(case, mode):
+    """The header's in-load transform (vd_conv_desc / vd_wgrad_desc in_scale, in_shift, in_slope): the activation operand is
+    leaky(x * s[c] + b[c]) applied in the gather, zero padding staying zero - i.e. the conv / weight gradient of the
+    transformed tensor (what a consumer would read if the producer's BatchNorm+LeakyReLU pass were skipped).  Off the
+    product path, but part of the C-ABI; the fp16 split has no such variant and must say so."""
+    from viddet_amd import ops, lib as L
+    n, ci, h, w, co, k, s, p = case
+    rng, x, wt = _mk(n, ci, h, w, co, k, 31)
+    sc, sh, slope = rng.uniform(0.5, 1.5, ci), rng.standard_normal(ci), 0.1
+    xt = R.leaky(x * sc.reshape(1, -1, 1, 1) + sh.reshape(1, -1, 1, 1), slope)
+    ref = R.conv2d(xt, wt, s, p)
+    ho, wo = ref.shape[2:]
+    out = torch.empty(n, ho, wo, co, device="cuda")
+    xd = nchw_to_dev_nhwc(x)
+    for tile in ((0, 1, 4) if not mode else (0, 2, 4, 11, 16 if co <= 64 else 12)):
+        out.zero_()
+        ops.conv_fwd(xd, _packed(wt, co), out, k=k, stride=s, pad=p, Co=co, tile=tile, split=mode,
+                     in_scale=dev(sc), in_shift=dev(sh), in_slope=slope)
+        torch.cuda.synchronize()
+        assert maxdiff(dev_nhwc_to_nchw(out), ref) < TOL, tile
+    dy = rng.standard_normal((n, co, ho, wo))
+    _, dw_ref = R.conv2d_backward(xt, wt, dy, s, p)
+    dwp = torch.empty(co, k * k * ci, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ops.conv_wgrad(xd, nchw_to_dev_nhwc(dy), dwp, ws, k=k, stride=s, pad=p, Co=co, split=mode,
+                   in_scale=dev(sc), in_shift=dev(sh), in_slope=slope)
+    dw = torch.empty(co, ci, k, k, device="cuda")
+    ops.unpack_weight(dwp, dw)
+    torch.cuda.synchronize()
+    assert maxdiff(dw.cpu().numpy(), dw_ref) < TOL * np.sqrt(n * ho * wo)
+    with pytest.raises(L.VidDetHipError):
+        ops.conv_fwd(xd, _packed(wt, co), out, k=k, stride=s, pad=p, Co=co, split='f16x2', in_scale=dev(sc), in_shift=dev(sh))
+
+
 def test_stem_im2col_conv_and_wgrad():
     from viddet_amd import ops
     n, h, w, co = 2, 24, 20, 32

@@ -114,8 +114,9 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
 
 def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
              leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0, split=False, amax_in=None, amax_w=None,
-             amax_out=None):
-    """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo]."""
+             amax_out=None, in_scale=None, in_shift=None, in_slope=0.1):
+    """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo].
+    in_scale / in_shift: per-input-channel transform leaky(x * s + b) applied in the operand gather (the padding stays zero)."""
     N, Hi, Wi, Ci = x.shape
     Ho = (Hi + 2 * pad - k) // stride + 1
     Wo = (Wi + 2 * pad - k) // stride + 1
@@ -123,12 +124,12 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
                taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
                residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile, split=split,
-               amax_in=amax_in, amax_w=amax_w, amax_out=amax_out)
+               amax_in=amax_in, amax_w=amax_w, amax_out=amax_out, in_scale=in_scale, in_shift=in_shift, in_slope=in_slope)
     return Ho, Wo
 
 
 def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0, split=False, amax_in=None,
-               amax_dout=None):
+               amax_dout=None, in_scale=None, in_shift=None, in_slope=0.1):
     """dwp [Co][T*Ci] (fwd-packed layout) = wgrad(x [N,Hi,Wi,Ci], dout [N,Ho,Wo,Co])."""
     N, Hi, Wi, Ci = x.shape
     _, Ho, Wo, ldd = dout.shape
@@ -139,6 +140,7 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     d.in_stride = stride
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
+    d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
     if split in ('f16x2', 'f16x2nh'):
         d.flags = MATH_F16X2
         amax_in = amax(x) if amax_in is None else amax_in
