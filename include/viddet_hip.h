@@ -141,7 +141,8 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
 /* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T,
                         void* stream);
-/* stem im2col into 64 bf16 columns per pixel (27 real), from [N,H,W,3] (nchw=0) or [N,3,H,W] (nchw=1) fp32 */
+/* stem im2col into 64 bf16 columns per pixel (27 real), from [N,H,W,3] (nchw=0) or [N,3,H,W] (nchw=1) fp32.
+ * Off the product path since vd_stem_conv (direct stem kernel): kept as the explicit lowering the tests compare with. */
 int vd_stem_im2col_bf16(const float* in, void* col, int N, int H, int W, int nchw, void* stream);
 
 /* Weight gradient (autograd.backward wrt nn.Conv2D weight, train_yolov3.py:631):

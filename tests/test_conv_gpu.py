@@ -351,3 +351,21 @@ def test_stem_direct_conv_forward_wgrad_stats(shape):
                 dwk[:, (ky * 3 + kx) * 3 + c] = dw_ref[:, c, ky, kx]
     assert maxdiff(got, dwk) < TOL * np.sqrt(n * h * w)
     assert float(np.abs(got[:, 27:]).max()) == 0.0
+
+
+def test_stem_im2col_bf16_and_nms_workspace_size():
+    """Two exports no other test reaches directly: the bf16 form of the explicit stem lowering (64 columns per pixel, 27
+    real) equals the fp32 one rounded to bf16, and the NMS workspace is one overflow flag per image."""
+    import ctypes as C
+    from viddet_amd import ops, lib as L
+    n, h, w = 2, 11, 9
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((n, 3, h, w))
+    col32 = torch.empty(n, h, w, 32, device="cuda")
+    ops.stem_im2col(dev(x), col32, nchw=True)
+    for nchw, src in ((1, dev(x)), (0, nchw_to_dev_nhwc(x))):
+        col = torch.full((n, h, w, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.check(L.load().vd_stem_im2col_bf16(src.data_ptr(), col.data_ptr(), n, h, w, nchw, L.stream_ptr()), "vd_stem_im2col_bf16")
+        torch.cuda.synchronize()
+        assert torch.equal(col[..., :27], col32[..., :27].to(torch.bfloat16)) and float(col[..., 27:].abs().max()) == 0.0
+    assert L.load().vd_nms_ws_bytes(5, 1000, 400) == 5 * 4
