@@ -194,7 +194,8 @@ def get_net(classes, rank_world):
     if FLAGS.mixup:
         # gluoncv.data.MixupDetection (absent offline) appends the mix ratio as a 7th label column, after which the
         # reference's video transform takes columns 4..4+num_classes - class id, 'difficult' flag and the ratio - as a
-        # multi-hot class vector (transforms.py:264-267).  The target generator here takes gt_mixratio
+        # multi-hot class vector (transforms.py:264-267), which its target generator then cannot broadcast into the class
+        # targets (yolo_target.py:128): with the 6-column labels of its own datasets the reference's --mixup does not run.  The target generator here takes gt_mixratio
         # (targets.prefetch_targets), but that label path is not one to reproduce: refuse instead of ignoring the flag.
         raise NotImplementedError("--mixup: the reference's mixup label path (gluoncv MixupDetection + transforms.py:264-267) is not built")
     k = int(FLAGS.window[0])
