@@ -112,6 +112,7 @@ class Program:
 
 
 _TUNE_CACHE = {}
+_PARITY_STREAMS = __import__('os').environ.get('VD_PARITY_STREAMS', '1') == '1'     # the four parity launches of a stride-2 data gradient on four streams (+1 % in same-box A/B)
 _FUSE_BWD_S2 = __import__('os').environ.get('VD_FUSE_BWD_S2', '1') == '1'   # A/B switch: fused BN-backward reductions in stride-2 data gradients
 
 
@@ -1731,6 +1732,17 @@ class YOLOV3(object):
             fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _FUSE_BWD_S2)) and
                             consumers[n.src][0] is n and pm.fr == n.fr) else None
             bs_rows = 0
+            # the four parity launches of a stride-2 data gradient write disjoint pixels and read the same dz: run them
+            # side by side on their own streams (VD_PARITY_STREAMS=1) so that they share dz in the L2s and fill each other's tails
+            par = None
+            if _PARITY_STREAMS and len(plans) == 4 and self.overlap_wgrad:
+                if getattr(self, '_par_streams', None) is None:
+                    self._par_streams = [torch.cuda.Stream() for _ in range(3)]
+                par = self._par_streams
+                e_fork = torch.cuda.Event()
+                seg.add_py(lambda e=e_fork: e.record(torch.cuda.current_stream()))
+                for st in par:
+                    seg.add_py(lambda e=e_fork, st=st: st.wait_event(e))
             for pi, plan in enumerate(plans):
                 assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
                 wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
@@ -1762,7 +1774,13 @@ class YOLOV3(object):
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
                     flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
-                    bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans))
+                    bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans),
+                    stream=(par[pi - 1] if (par is not None and pi > 0) else None))
+                if par is not None and pi == len(plans) - 1:
+                    for st in par:                                  # join before anything reads d:src or the partial table
+                        e_join = torch.cuda.Event()
+                        seg.add_py(lambda e=e_join, st=st: e.record(st))
+                        seg.add_py(lambda e=e_join: torch.cuda.current_stream().wait_event(e))
                 if fuse_m is not None and pi == len(plans) - 1:
                     seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
                             fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
