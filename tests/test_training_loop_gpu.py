@@ -13,11 +13,19 @@ from tests.util import dev
 pytestmark = pytest.mark.gpu
 
 
-def _loop(math, steps, c=4, size=128, B=4, lr=1e-3):
+def _loop(math, steps, c=4, size=128, B=4, lr=1e-3, ulp=False):
     from viddet_amd import model as M
     M.set_conv_math(math)
     try:
         net, P = _mk_net(c, 21, obj_bias=-1.0)
+        if ulp:
+            # every conv weight moved by -1 / 0 / +1 unit in the last place (a perturbation of fp32 rounding size)
+            g = np.random.default_rng(5)
+            for k, p in net.collect_params().items():
+                if k.endswith("weight"):
+                    w = P[k].astype(np.float32)
+                    step = np.where(w == 0, 0, g.integers(-1, 2, w.shape)).astype(np.int32)
+                    p.set_data(torch.from_numpy((w.view(np.int32) + step).view(np.float32)))
         rng = np.random.default_rng(21)
         x = rng.standard_normal((B, 3, size, size)).astype(np.float32)
         gt, tg = _targets(rng, B, c, size, 2)
@@ -61,15 +69,45 @@ def test_fixed_batch_loss_falls_and_the_trained_net_finds_its_boxes():
     assert total >= 4 and found >= total - 1, (found, total)
 
 
-def test_product_arithmetics_share_the_trajectory():
-    _, h_auto, _ = _loop(None, 12)
-    _, h_native, _ = _loop("native", 12)
-    _, h_split, _ = _loop("split", 12)
-    ta, tn, ts = h_auto.sum(1), h_native.sum(1), h_split.sum(1)
-    print("summed loss after 12 steps: auto %.3f native %.3f 3-way split %.3f" % (ta[-1], tn[-1], ts[-1]))
-    # identical weights at step 0: the first losses agree to fp32 round-off; then the runs drift apart slowly
-    assert abs(ta[0] - tn[0]) < 2e-4 * tn[0] and abs(ts[0] - tn[0]) < 2e-4 * tn[0]
-    # (measured: 1e-9, 5e-6, 3e-4, 1e-3, 5e-3, 2e-2 relative over the first six steps; once the loss plateaus under this
-    # learning rate the runs oscillate independently)
-    assert np.all(np.abs(ta - tn)[:6] < 0.03 * tn[:6]) and np.all(np.abs(ts - tn)[:6] < 0.03 * tn[:6]), (ta, tn, ts)
-    assert np.all(np.abs(ta - tn) < 0.6 * tn) and np.all(np.abs(ts - tn) < 0.6 * tn), (ta, tn, ts)
+def _pinned(monkeypatch, alt=False):
+    """Deterministic kernels: no timing-based autotuner, the kernels' heuristic tiles (or the second fixed tile set)."""
+    monkeypatch.setenv("VD_AUTOTUNE", "0")
+    monkeypatch.setenv("VD_TILE_ALT", "1" if alt else "0")
+
+
+def test_product_arithmetics_share_the_trajectory(monkeypatch):
+    """train_yolov3.py:623-640 as a loop under each fp32-grade product arithmetic, every run with PINNED kernels
+    (VD_AUTOTUNE=0: which tile and arithmetic a launch uses no longer depends on the box's timings).  A loop that drops the
+    loss 1331 -> 70 in four steps amplifies any rounding-level difference ~10x per step, so no fixed bound on
+    |split - native| after step 1 means anything by itself; what IS boundable is the rate: the split arithmetics must drift
+    from the fp32 MFMA's trajectory no faster than the fp32 MFMA drifts from ITSELF under perturbations of rounding size -
+    controls: (a) the same arithmetic under a second tile set (other groupings of the BatchNorm partial sums and split-K
+    slabs), (b) every weight moved by at most one unit in the last place."""
+    steps = 8
+    _pinned(monkeypatch)
+    _, h_native, _ = _loop("native", steps)
+    _, h_again, _ = _loop("native", steps)
+    _, h_split, _ = _loop("split", steps)
+    _, h_f16, _ = _loop("split2", steps)
+    _, h_ulp, _ = _loop("native", steps, ulp=True)
+    _pinned(monkeypatch, alt=True)
+    _, h_alt, _ = _loop("native", steps)
+    tn, ts, tf, tu, tt = [h.sum(1) for h in (h_native, h_split, h_f16, h_ulp, h_alt)]
+    rel = lambda t: np.abs(t - tn) / tn
+    for name, t in (("3-way bf16 split", ts), ("2-way fp16 split", tf), ("control: 1-ulp weights", tu), ("control: tile set 2", tt)):
+        print("%-24s |loss - native| / native per step: %s" % (name, " ".join("%.1e" % v for v in rel(t))))
+    # pinned kernels are deterministic: the same run twice is the same bits (nothing timing-dependent is left)
+    assert np.array_equal(h_native, h_again)
+    # identical weights at step 0: the first losses agree to fp32 round-off for every arithmetic, and after one update still
+    assert np.all(rel(ts)[:2] < 2e-4) and np.all(rel(tf)[:2] < 2e-4), (rel(ts)[:2], rel(tf)[:2])
+    # the rate: at every step the split runs are no further from native than 32x the larger control has been so far
+    # (32x = one and a half steps of the ~10x-per-step amplification; a bf16-grade product would start 1e4 x the
+    # controls and stay there), plus the round-off floor of the loss sum itself
+    ctrl = np.maximum.accumulate(np.maximum(rel(tu), rel(tt)))
+    assert ctrl[0] < 2e-4
+    for name, t in (("split", ts), ("split2", tf)):
+        bad = rel(t) > 32.0 * ctrl + 1e-6
+        assert not bad.any(), (name, rel(t), ctrl)
+    # and none of them leaves the neighbourhood of the trajectory
+    for t in (ts, tf, tu, tt):
+        assert np.all(np.abs(t - tn) < 0.6 * tn), (t, tn)

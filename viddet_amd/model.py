@@ -185,6 +185,13 @@ def autotune_desc(d, reps=3):
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
         f16 = L.MATH_F16X2 if (d.amax_in and d.amax_w and not d.in_scale) else L.MATH_SPLIT
         d.flags = base | {"split": L.MATH_SPLIT, "split2": f16, "bf16": L.MATH_BF16}.get(math, 0)
+        if os.environ.get("VD_TILE_ALT", "0") == "1":
+            # a second, equally deterministic tile set (the last candidate of the launch record's list instead of the
+            # kernel's heuristic tile): other M-tile heights, hence other groupings of the BatchNorm partial sums and
+            # split-K slabs - the control of tests/test_training_loop_gpu.py
+            alt = [t for fl, t in _tile_candidates(d, math if math != "auto" else "native") if fl == (d.flags & _ALL_MATH)]
+            if alt:
+                d.tile = alt[-1]
         return
     lib = L.load()
     s = L.stream_ptr()
