@@ -147,9 +147,17 @@ def test_train_script_default_path(tmp_path, monkeypatch):
     net2 = T.main(["--batch_size", "2", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "2", "--save_prefix", "0000",
                    "--trained_on", "coco", "--no_random_shape", "--val_interval", "1000"])
     assert len(net2.classes) == 20 and net2.collect_params()["yolo_outputs.0.prediction.weight"].shape[0] == 75
-    with pytest.raises(NotImplementedError):
+    # --mixup (train_yolov3.py:227-229,571-581): pair blending + mix ratios as objectness targets in epoch 0, switched off
+    # in the last epoch(s) (--no_mixup_epochs); two one-batch epochs, worker processes on
+    net3 = T.main(["--batch_size", "4", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "4", "--save_prefix", "0000",
+                   "--mixup", "--no_mixup_epochs", "0", "--no_random_shape", "--val_interval", "1000", "--num_workers", "2",
+                   "--log_interval", "1"])
+    log = (pre / "yolo3_darknet53_voc_train.log").read_text()
+    assert "[Epoch 1][Batch 0/1]" in log
+    assert all(bool(torch.isfinite(p.data()).all()) for p in net3.collect_params().values())
+    with pytest.raises(NotImplementedError):               # MixupDetection blends single frames
         T.main(["--batch_size", "2", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "2", "--save_prefix", "0000",
-                "--mixup", "--no_random_shape"])
+                "--mixup", "--no_random_shape", "--dataset", "vid", "--window", "3,1"])
     # a second start on the same prefix is refused unless it is '0000' (train_yolov3.py:713-723)
     (tmp_path / "models" / "experiments" / "0007").mkdir(parents=True)
     with pytest.raises(SystemExit):
@@ -177,7 +185,7 @@ def test_train_script_steps_equal_the_protocol_loop(tmp_path, monkeypatch, no_wd
     M._TUNE_CACHE.clear()
     size, bs, seed, lr = 96, 4, 233, 0.01
     args = ["--batch_size", str(bs), "--data_shape", str(size), "--epochs", "1", "--synthetic_samples", str(bs),
-            "--save_prefix", "0000", "--val_interval", "1000", "--lr", str(lr), "--no_random_shape"] + (["--no_wd"] if no_wd else [])
+            "--save_prefix", "0000", "--val_interval", "1000", "--lr", str(lr), "--no_random_shape", "--num_workers", "0"] + (["--no_wd"] if no_wd else [])
     net = T.main(args)
     # the batches the script saw: same dataset, transform and loader seeds (train_yolov3.py get_dataset / get_dataloader)
     ds = SyntheticDetection("voc", num_samples=bs, seed=seed)

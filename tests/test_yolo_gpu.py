@@ -162,6 +162,7 @@ def _gt(rng, b, m, size, c, nvalid):
     dict(b=1, c=30, size=416, m=8, nvalid=[8], smooth=False, seed=34),           # full 416 grid
     dict(b=2, c=285, size=96, m=5, nvalid=[4, 2], smooth=False, seed=35),        # combined set: 285 classes
     dict(b=1, c=285, size=608, m=8, nvalid=[8], smooth=True, seed=36),           # ... one full 608x608 frame, smoothed
+    dict(b=2, c=20, size=128, m=6, nvalid=[6, 3], smooth=False, seed=37, mix=True),   # --mixup: objectness targets = mix ratios
 ])
 def test_loss_fwd_bwd(cfg):
     from viddet_amd import ops
@@ -171,8 +172,13 @@ def test_loss_fwd_bwd(cfg):
     heads = _heads(rng, b, c, grids, -1.0)
     gt, ids = _gt(rng, b, m, size, c, cfg["nvalid"])
     # make some predictions overlap a gt strongly so the ignore branch (IoU > 0.7) is exercised
-    targets = Y.prefetch_targets(size, size, grids, gt, ids, c)
+    # --mixup (yolo_target.py:124-125): a positive's objectness target is its box's mix ratio in (0, 1) - it then weights
+    # the objectness term, the box terms and the class mask
+    mix = rng.uniform(0.05, 0.95, (b, m, 1)) if cfg.get("mix") else None
+    targets = Y.prefetch_targets(size, size, grids, gt, ids, c, mix)
     obj_t, ctr_t, scl_t, wgt_t, cls_t = targets
+    if mix is not None:
+        assert ((obj_t > 0) & (obj_t < 1)).sum() >= sum(cfg["nvalid"]) - 2
     # oracle
     outs = [Y.yolo_output(hh, c, Y.OUT_ANCHORS[s], Y.OUT_STRIDES[s], training=True) for s, hh in enumerate(heads)]
     box = np.concatenate([o[0] for o in outs], axis=1)

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from viddet_amd import dist as vdist
-from viddet_amd.data import (SyntheticDetection, YOLO3VideoTrainTransform, YOLO3VideoInferenceTransform, Loader,
+from viddet_amd.data import (SyntheticDetection, MixupDetection, YOLO3VideoTrainTransform, YOLO3VideoInferenceTransform, Loader,
                              FeatureDataset, YOLO3NBVideoTrainTransform, YOLO3NBVideoInferenceTransform)
 from viddet_amd.metrics import VOCMApMetric, VOCMApMetricTemporal, LossMetric
 from viddet_amd.model import yolo3_darknet53, yolo3_no_backbone
@@ -127,6 +127,10 @@ def get_dataset(dataset_name, dataset_val_name, save_prefix=""):
         val_metric = VOCMApMetric(iou_thresh=0.5, class_names=val_ds.classes)
     if FLAGS.num_samples < 0:
         FLAGS.num_samples = len(train_ds)
+    if FLAGS.mixup:                                    # :227-229
+        if int(FLAGS.window[0]) > 1 or FLAGS.features_dir is not None:
+            raise NotImplementedError("--mixup blends single frames (gluoncv MixupDetection): not with --window k > 1 / --features_dir")
+        train_ds = MixupDetection(train_ds)
     return train_ds, val_ds, val_metric
 
 
@@ -142,11 +146,11 @@ def get_dataloader(train_dataset, val_dataset, data_shape, batch_size, rank, wor
         return train_loader, val_loader
     rng = Rng.seeded(FLAGS.seed + rank)
     if FLAGS.no_random_shape:                          # :258-262
-        tf = YOLO3VideoTrainTransform(w, h, train_dataset.num_class, rng)
+        tf = YOLO3VideoTrainTransform(w, h, train_dataset.num_class, rng, mixup=FLAGS.mixup)
     else:                                              # :263-271 the default: a random side of 320 ... 608 every 10 batches
-        tf = [YOLO3VideoTrainTransform(x * 32, x * 32, train_dataset.num_class, rng) for x in range(10, 20)]
+        tf = [YOLO3VideoTrainTransform(x * 32, x * 32, train_dataset.num_class, rng, mixup=FLAGS.mixup) for x in range(10, 20)]
     train_loader = Loader(train_dataset, tf, per_rank, train=True, shuffle=True, seed=FLAGS.seed, rank=rank, world=world,
-                          interval=FLAGS.random_shape_interval)
+                          interval=FLAGS.random_shape_interval, num_workers=FLAGS.num_workers)
     # validation frames travel as uint8 and are normalised on the device (same arithmetic, a quarter of the bytes)
     val_loader = Loader(val_dataset, YOLO3VideoInferenceTransform(w, h, device_normalize=True), per_rank, train=False,
                         last_batch="keep", rank=rank, world=world)
@@ -191,13 +195,6 @@ def get_net(classes, rank_world):
     for flag in ("new_model", "motion_stream", "rnn_pos", "corr_pos"):
         if getattr(FLAGS, flag):
             raise NotImplementedError("--%s selects a research variant outside the yolo3_darknet53 hot path" % flag)
-    if FLAGS.mixup:
-        # gluoncv.data.MixupDetection (absent offline) appends the mix ratio as a 7th label column, after which the
-        # reference's video transform takes columns 4..4+num_classes - class id, 'difficult' flag and the ratio - as a
-        # multi-hot class vector (transforms.py:264-267), which its target generator then cannot broadcast into the class
-        # targets (yolo_target.py:128): with the 6-column labels of its own datasets the reference's --mixup does not run.  The target generator here takes gt_mixratio
-        # (targets.prefetch_targets), but that label path is not one to reproduce: refuse instead of ignoring the flag.
-        raise NotImplementedError("--mixup: the reference's mixup label path (gluoncv MixupDetection + transforms.py:264-267) is not built")
     k = int(FLAGS.window[0])
     if FLAGS.features_dir is not None:                 # :335-342
         net = yolo3_no_backbone(classes, norm_layer="syncbn" if FLAGS.syncbn and rank_world[1] > 1 else None,
@@ -287,6 +284,11 @@ def train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, st
             best_map = [float(f.readlines()[-1].split()[1])]
     num_update = 0
     for epoch in range(start_epoch, FLAGS.epochs + 1):
+        if FLAGS.mixup:                                 # :571-581 beta(1.5, 1.5) blends, switched off for the last epochs
+            if epoch >= FLAGS.epochs - FLAGS.no_mixup_epochs:
+                train_dataset.set_mixup(None)
+            else:
+                train_dataset.set_mixup(np.random.beta, 1.5, 1.5)
         st = tic = btic = time.time()
         i = -1
         batch_size = FLAGS.batch_size
@@ -345,6 +347,9 @@ def main(argv=None):
     global FLAGS
     FLAGS = parse_flags(argv)
     FLAGS.window = [int(s) for s in FLAGS.window]
+    if FLAGS.num_workers < 0:                           # :694-695 (here capped: the transforms are NumPy, not OpenCV threads)
+        import multiprocessing
+        FLAGS.num_workers = min(multiprocessing.cpu_count(), 8)
     if FLAGS.window[0] > 1:
         assert "vid" in FLAGS.dataset, "If using window size >1 you can only use the vid dataset"
     else:

@@ -92,6 +92,50 @@ class SyntheticCombined(SyntheticDetection):
         return img, lab
 
 
+class MixupDetection:
+    """gluoncv.data.MixupDetection as train_yolov3.py:227-229 wraps the training set with --mixup (the class is not in
+    /root/reference; restated from gluoncv/data/mixup/detection.py, [UPSTREAM-UNVERIFIED]): with a mix function set
+    (`set_mixup(np.random.beta, 1.5, 1.5)`, train_yolov3.py:571-581) a sample is the pixel blend
+    lambda * img1 + (1 - lambda) * img2 of frame `idx` and one other frame on a canvas of the larger height / width
+    (uint8 again), its label both frames' rows with a 7th column = the row's mix ratio (lambda or 1 - lambda).  lambda is
+    clipped to [0, 1]; lambda >= 1 (or no mix function) returns frame `idx` with a column of ones.  Draws: the mix
+    function, then np.random.choice over the other indices - numpy's global generator, as upstream (or `rng`)."""
+
+    def __init__(self, dataset, mixup=None, *args, rng=None):
+        self._dataset, self._mixup, self._mixup_args = dataset, mixup, args
+        self._rng = rng                                      # None = numpy's global generator
+        self.classes, self.num_class = dataset.classes, dataset.num_class
+
+    def set_mixup(self, mixup=None, *args):
+        self._mixup, self._mixup_args = mixup, args
+
+    def __len__(self):
+        return len(self._dataset)
+
+    def sample_path(self, idx):
+        return self._dataset.sample_path(idx)
+
+    def __getitem__(self, idx):
+        img1, label1 = self._dataset[idx]
+        if np.ndim(img1) != 3 or isinstance(label1, (list, tuple)):
+            raise NotImplementedError("MixupDetection blends single (h,w,3) frames; windows (--window k > 1) have no mixup upstream either")
+        lambd = 1.0
+        if self._mixup is not None:
+            lambd = max(0.0, min(1.0, float(self._mixup(*self._mixup_args))))
+        if lambd >= 1:
+            return img1, np.hstack((label1, np.ones((label1.shape[0], 1))))
+        choice = (np.random if self._rng is None else self._rng).choice
+        idx2 = int(choice(np.delete(np.arange(len(self)), idx)))
+        img2, label2 = self._dataset[idx2]
+        height, width = max(img1.shape[0], img2.shape[0]), max(img1.shape[1], img2.shape[1])
+        mix = np.zeros((height, width, 3), dtype=np.float32)
+        mix[:img1.shape[0], :img1.shape[1], :] = img1.astype(np.float32) * np.float32(lambd)
+        mix[:img2.shape[0], :img2.shape[1], :] += img2.astype(np.float32) * np.float32(1.0 - lambd)
+        y1 = np.hstack((label1, np.full((label1.shape[0], 1), lambd)))
+        y2 = np.hstack((label2, np.full((label2.shape[0], 1), 1.0 - lambd)))
+        return mix.astype(np.uint8), np.vstack((y1, y2))       # astype('uint8') truncates, as mx.nd's cast does
+
+
 def _to_tensor_normalize(img):
     x = img.astype(np.float32) / 255.0            # mx.nd.image.to_tensor (any input dtype is divided by 255)
     x = (x - MEAN) / STD                          # mx.nd.image.normalize
@@ -128,8 +172,14 @@ class YOLO3VideoTrainTransform:
     same distortion / crop / flip.  `rng`: viddet_amd.video.Rng (numpy + python generators; default = a private pair
     seeded with 0; Rng() = the global modules, exactly the reference's sources)."""
 
-    def __init__(self, width, height, num_class, rng=None, augment=True, device_normalize=False):
-        self._w, self._h, self._c = width, height, num_class
+    def __init__(self, width, height, num_class, rng=None, augment=True, device_normalize=False, mixup=False):
+        """mixup (transforms.py:166,264-270): the labels carry a last column of mix ratios (MixupDetection), which goes to
+        the target generator as gt_mixratio -> the objectness target (yolo_target.py:124-125).  The class id is column 4,
+        as in gluoncv's YOLO3DefaultTrainTransform, which this transform was derived from: the reference's own test
+        `bbox.shape[-1] == 6` (transforms.py:261) sends 7-column labels down its multi-hot branch, whose 3-wide slice
+        (class, difficult, ratio) its target generator cannot broadcast into C class targets (yolo_target.py:128) - the
+        reference's --mixup stops there for every C != 3."""
+        self._w, self._h, self._c, self._mixup = width, height, num_class, bool(mixup)
         if rng is None:
             rng = Rng.seeded(0)
         elif isinstance(rng, np.random.Generator):             # an older call form: derive the pair from the generator
@@ -166,14 +216,16 @@ class YOLO3VideoTrainTransform:
         if len(bboxs) > 1:
             # per-frame labels (--mult_out, transforms.py:252-294): targets of every frame stacked on a leading t axis,
             # gt boxes (t, M, 4) padded with -1
-            tg = [prefetch_targets(self._h, self._w, b[np.newaxis, :, :4], b[np.newaxis, :, 4:5], self._c) for b in bboxs]
+            tg = [prefetch_targets(self._h, self._w, b[np.newaxis, :, :4], b[np.newaxis, :, 4:5], self._c,
+                                   b[np.newaxis, :, -1:] if self._mixup else None) for b in bboxs]
             cols = [np.concatenate([t[i] for t in tg], axis=0) for i in range(5)]
             gt = pad_stack([np.asarray(b[:, :4], dtype=np.float32) for b in bboxs])
             return (x,) + tuple(cols) + (gt,)
         b0 = np.asarray(bboxs[0])                                         # :269-271 one label set: un-stacked targets
         gt = b0[np.newaxis, :, :4]
         ids = b0[np.newaxis, :, 4:5]
-        obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c)
+        obj, ctr, scl, wgt, cls = prefetch_targets(self._h, self._w, gt, ids, self._c,
+                                                   b0[np.newaxis, :, -1:] if self._mixup else None)
         return x, obj[0], ctr[0], scl[0], wgt[0], cls[0], gt[0].astype(np.float32)
 
 
@@ -256,8 +308,13 @@ class Loader:
     the workers' own draws, so the reference's sequence of shapes is not reproducible either."""
 
     def __init__(self, dataset, transform, batch_size, train, shuffle=False, last_batch="rollover", seed=0,
-                 rank=0, world=1, interval=10):
+                 rank=0, world=1, interval=10, num_workers=0):
         self.ds, self.tf, self.bs, self.train = dataset, transform, batch_size, train
+        # num_workers > 0: samples are read and transformed in that many worker processes (the reference's
+        # DataLoader(num_workers=...), train_yolov3.py:242-280), one batch ahead of the consumer.  Every worker re-seeds
+        # the transforms' random pair with (seed, rank, worker) - as with the reference's workers the augmentation draws
+        # are then per worker, not one global sequence; num_workers = 0 keeps the single deterministic sequence.
+        self.num_workers, self._seed, self._pool = max(0, int(num_workers)), seed, None
         self.shuffle, self.last_batch, self._rng = shuffle, last_batch, np.random.default_rng(seed)
         self.rank, self.world = rank, world
         self.tfs = list(transform) if isinstance(transform, (list, tuple)) else None
@@ -279,16 +336,89 @@ class Loader:
         if self.shuffle:
             self._rng.shuffle(idx)
         idx = idx[self.rank::self.world]                 # frames are sharded across ranks, windows never split
+        if self.num_workers > 0:
+            yield from self._iter_workers(idx)
+            return
         for i in range(len(self)):
             chunk = idx[i * self.bs:(i + 1) * self.bs]
             if self.tfs is not None and i % self.interval == 0:
                 self.tf = self.tfs[int(self._choice.randint(len(self.tfs)))]
-            if self.train:
-                # Stack every column, Pad(-1) the trailing gt boxes (train_yolov3.py:238 / :252: 8+1 columns with
-                # cached features, 6+1 with frames)
-                cols = list(zip(*[self.tf(*self.ds[int(j)]) for j in chunk]))
-                yield [np.stack(c) for c in cols[:-1]] + [pad_stack(cols[-1])]
-            else:
-                # (data..., Pad(-1) labels, sample index): 1 data column for frames, 3 for cached features
-                cols = list(zip(*[self.tf(*self.ds[int(j)], int(j)) for j in chunk]))
-                yield tuple(np.stack(c) for c in cols[:-2]) + (pad_stack(cols[-2]), np.asarray(cols[-1]))
+            yield self._collate(self._samples(chunk, self.tf))
+
+    def _collate(self, samples):
+        cols = list(zip(*samples))
+        if self.train:
+            # Stack every column, Pad(-1) the trailing gt boxes (train_yolov3.py:238 / :252: 8+1 columns with
+            # cached features, 6+1 with frames)
+            return [np.stack(c) for c in cols[:-1]] + [pad_stack(cols[-1])]
+        # (data..., Pad(-1) labels, sample index): 1 data column for frames, 3 for cached features
+        return tuple(np.stack(c) for c in cols[:-2]) + (pad_stack(cols[-2]), np.asarray(cols[-1]))
+
+    def _samples(self, chunk, tf):
+        if self.train:
+            return [tf(*self.ds[int(j)]) for j in chunk]
+        return [tf(*self.ds[int(j)], int(j)) for j in chunk]
+
+    # ---- worker processes -----------------------------------------------------------------------------------------
+    def _iter_workers(self, idx):
+        """The same batches as the single-process loop, produced by the pool one batch ahead."""
+        if self._pool is None:
+            import multiprocessing as mp
+            # fresh interpreters (spawn), not forks of this process: it has the GPU open, its children must not inherit
+            # that; viddet_amd.data imports NumPy only, so a worker starts in a fraction of a second
+            ctx = mp.get_context("spawn")
+            counter = ctx.Value("i", 0)
+            self._pool = ctx.Pool(self.num_workers, initializer=_worker_init,
+                                  initargs=(self.ds, self.tfs if self.tfs is not None else [self.tf], self.train,
+                                            self._seed * 1000003 + self.rank * 1009, counter))
+        pending = None
+        for i in range(len(self)):
+            chunk = idx[i * self.bs:(i + 1) * self.bs]
+            if self.tfs is not None and i % self.interval == 0:
+                self.tf = self.tfs[int(self._choice.randint(len(self.tfs)))]
+            ti = self.tfs.index(self.tf) if self.tfs is not None else 0
+            # the dataset's mix function travels with every task: train_yolov3.py:571-581 switches it per epoch on the
+            # parent's copy, the workers hold their own
+            mix = (self.ds._mixup, self.ds._mixup_args) if isinstance(self.ds, MixupDetection) else None
+            nxt = self._pool.map_async(_worker_sample, [(ti, int(j), mix) for j in chunk])
+            if pending is not None:
+                yield self._collate(pending.get())
+            pending = nxt
+        if pending is not None:
+            yield self._collate(pending.get())
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool.join()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_WORKER = {}
+
+
+def _worker_init(ds, tfs, train, seed, counter):
+    import random as _pyrandom
+    with counter.get_lock():
+        wid = counter.value
+        counter.value += 1
+    _WORKER.update(ds=ds, tfs=tfs, train=train)
+    np.random.seed((seed + wid) % (2 ** 32))             # the global modules (Rng() transforms draw from them)
+    _pyrandom.seed(seed + wid)
+    for t in tfs:                                        # private pairs: one sequence per worker
+        if getattr(t, "_rng", None) is not None:
+            t._rng = Rng.seeded((seed + wid) % (2 ** 32))
+
+
+def _worker_sample(task):
+    ti, j, mix = task
+    tf, ds = _WORKER["tfs"][ti], _WORKER["ds"]
+    if mix is not None:
+        ds.set_mixup(mix[0], *mix[1])
+    return tf(*ds[j]) if _WORKER["train"] else tf(*ds[j], j)

@@ -27,10 +27,7 @@ from . import ops
 from .lib import ConvDesc, WgradDesc, EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL
 from .ops import round_up, fwd_taps, dgrad_plans
 
-# models/definitions/yolo/wrappers.py:80-84
-ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
-STRIDES = [8, 16, 32]
-BN_EPS, BN_MOMENTUM, LEAKY_SLOPE = 1e-5, 0.9, 0.1   # layers.py:68-69
+from .consts import ANCHORS, STRIDES, BN_EPS, BN_MOMENTUM, LEAKY_SLOPE   # wrappers.py:80-84, layers.py:68-69
 
 
 class Slot:

@@ -8,7 +8,7 @@ only each scale's own 3 anchors are materialised.
 """
 import numpy as np
 
-from .model import ANCHORS, STRIDES
+from .consts import ANCHORS, STRIDES      # (not .model: the loader's worker processes stay NumPy-only)
 
 _OUT_ANCHORS = np.asarray(ANCHORS[::-1], dtype=np.float64).reshape(9, 2)   # stride 32 anchors first
 

@@ -15,6 +15,7 @@ below follow OpenCV's sampling convention (pixel centres: src = (dst + 0.5) * sc
 a = -0.75; Lanczos a = 4; INTER_AREA = coverage-weighted box average when shrinking), in float arithmetic - not OpenCV's
 fixed-point uint8 paths, so uint8 results can differ from cv2 by one grey level.
 """
+import functools
 import random as _pyrandom
 
 import numpy as np
@@ -121,23 +122,23 @@ def _lanczos_w(t, a=4):
     return out
 
 
-def _axis_weights(n_in, n_out, interp):
-    """Dense (n_out, n_in) resampling matrix of one axis."""
-    W = np.zeros((n_out, n_in))
+@functools.lru_cache(maxsize=256)
+def _axis_taps(n_in, n_out, interp):
+    """Sparse resampling operator of one axis: (idx (n_out, T) int64, w (n_out, T) float64) with
+    out[d] = sum_k w[d, k] * in[idx[d, k]]; indices are clipped to the axis (replicated border: OpenCV's convention), so
+    one source pixel may appear under several taps.  Cached per (n_in, n_out, interp): the training loader draws from a
+    handful of shapes (train_yolov3.py:262-271)."""
     scale = n_in / n_out
     d = np.arange(n_out)
     if interp == 0:                                          # nearest: floor(dst * scale)
-        W[d, np.minimum((d * scale).astype(np.int64), n_in - 1)] = 1.0
-        return W
+        return np.minimum((d * scale).astype(np.int64), n_in - 1)[:, None], np.ones((n_out, 1))
     if interp == 2 and n_out < n_in:                         # area, shrinking: coverage of [d*scale, (d+1)*scale)
-        lo, hi = d * scale, (d + 1) * scale
-        for i in range(n_out):
-            a, b = lo[i], min(hi[i], n_in)
-            j0, j1 = int(np.floor(a)), int(np.ceil(b))
-            for j in range(j0, j1):
-                W[i, j] = min(b, j + 1) - max(a, j)
-            W[i] /= W[i].sum()
-        return W
+        lo, hi = d * scale, np.minimum((d + 1) * scale, n_in)
+        T = int(np.ceil(scale)) + 1
+        j = np.floor(lo).astype(np.int64)[:, None] + np.arange(T)[None, :]
+        w = np.clip(np.minimum(hi[:, None], j + 1) - np.maximum(lo[:, None], j), 0.0, None)
+        w /= w.sum(axis=1, keepdims=True)
+        return np.clip(j, 0, n_in - 1), w
     f = (d + 0.5) * scale - 0.5
     if interp in (1, 2):                                     # bilinear (area when enlarging = bilinear)
         taps, wf = 2, lambda t: np.maximum(0.0, 1.0 - np.abs(t))
@@ -147,14 +148,30 @@ def _axis_weights(n_in, n_out, interp):
         taps, wf = 8, _lanczos_w
     else:
         raise ValueError("interp %r" % (interp,))
-    base = np.floor(f).astype(np.int64) - (taps // 2 - 1)
-    for k in range(taps):
-        j = base + k
-        w = wf(f - j)
-        np.add.at(W, (d, np.clip(j, 0, n_in - 1)), w)        # replicated border
+    j = (np.floor(f).astype(np.int64) - (taps // 2 - 1))[:, None] + np.arange(taps)[None, :]
+    w = wf(f[:, None] - j)
     if interp == 4:
-        W /= W.sum(axis=1, keepdims=True)
+        w = w / w.sum(axis=1, keepdims=True)
+    return np.clip(j, 0, n_in - 1), w
+
+
+def _axis_weights(n_in, n_out, interp):
+    """Dense (n_out, n_in) form of `_axis_taps` (tests; small shapes)."""
+    idx, w = _axis_taps(n_in, n_out, interp)
+    W = np.zeros((n_out, n_in))
+    np.add.at(W, (np.arange(n_out)[:, None].repeat(idx.shape[1], 1), idx), w)
     return W
+
+
+def _resample_axis(x, axis, idx, w):
+    """out = sum_k w[:, k] * take(x, idx[:, k], axis): T gathers of the whole array, no (n_out, n_in) matrix."""
+    shape = [1] * x.ndim
+    shape[axis] = idx.shape[0]
+    out = None
+    for k in range(idx.shape[1]):
+        t = np.take(x, idx[:, k], axis=axis) * w[:, k].reshape(shape)
+        out = t if out is None else out + t
+    return out
 
 
 def imresize(img, w, h, interp=1, rng=None):
@@ -175,8 +192,12 @@ def imresize(img, w, h, interp=1, rng=None):
         xs = np.minimum((np.arange(w) * (w0 / w)).astype(np.int64), w0 - 1)
         out = x[ys][:, xs]
     else:
-        Wy, Wx = _axis_weights(h0, h, interp), _axis_weights(w0, w, interp)
-        out = np.einsum('ij,jkc->ikc', Wy, np.einsum('xk,jkc->jxc', Wx, x))
+        # separable: the axis that shrinks more goes first (fewer elements for the second pass)
+        ty, tx = _axis_taps(h0, h, interp), _axis_taps(w0, w, interp)
+        if w * h0 <= h * w0:
+            out = _resample_axis(_resample_axis(x, 1, *tx), 0, *ty)
+        else:
+            out = _resample_axis(_resample_axis(x, 0, *ty), 1, *tx)
     if img.dtype == np.uint8:
         return np.clip(np.rint(out), 0, 255).astype(np.uint8)
     return out.astype(np.float32)
