@@ -111,3 +111,44 @@ def test_product_arithmetics_share_the_trajectory(monkeypatch):
     # and none of them leaves the neighbourhood of the trajectory
     for t in (ts, tf, tu, tt):
         assert np.all(np.abs(t - tn) < 0.6 * tn), (t, tn)
+
+
+def test_tuning_table_persists_and_a_second_start_is_bit_identical(tmp_path, monkeypatch):
+    """VD_TUNE_CACHE: the autotuner's choices are written when a plan is built and read by the next start, which then times
+    nothing and repeats the first run bit for bit (with choices made by timing, two runs of one seed used to differ)."""
+    from viddet_amd import model as M
+    path = tmp_path / "tune.json"
+    monkeypatch.setenv("VD_TUNE_CACHE", str(path))
+    monkeypatch.setenv("VD_AUTOTUNE", "1")
+    M._TUNE_CACHE.clear()
+    t0 = M._TUNE_CACHE.tuned
+    net1, h1, _ = _loop(None, 3)
+    assert M._TUNE_CACHE.tuned - t0 > 20 and path.exists()
+    import json
+    doc = json.load(open(path))
+    assert doc["library"] == M.TuneCache.library_id() and len(doc["entries"]) >= M._TUNE_CACHE.tuned - t0
+    M._TUNE_CACHE.clear()                                   # a second process start: nothing in memory
+    t1 = M._TUNE_CACHE.tuned
+    net2, h2, _ = _loop(None, 3)
+    assert M._TUNE_CACHE.tuned == t1, "the second start timed kernels again"
+    assert np.array_equal(h1, h2)
+    assert torch.equal(net1.weights, net2.weights) and torch.equal(net1.momentum_buf, net2.momentum_buf)
+    M._TUNE_CACHE.clear()
+
+
+def test_parity_streams_do_not_change_a_bit(monkeypatch):
+    """The four parity launches of a stride-2 data gradient write disjoint outputs and disjoint rows of the BatchNorm
+    partial table: on four streams (VD_PARITY_STREAMS=1, the default) or one after the other, same bits - a race on the
+    shared table or on d:src would show here.  The fused stride-2 reductions (VD_FUSE_BWD_S2) sum the same terms in
+    another kernel: round-off apart."""
+    _pinned(monkeypatch)
+    res = {}
+    for ps, fs in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("VD_PARITY_STREAMS", ps)
+        monkeypatch.setenv("VD_FUSE_BWD_S2", fs)
+        net, hist, _ = _loop("split2", 2)
+        res[(ps, fs)] = (hist, net.grads.clone(), net.weights.clone())
+    a, b, c = res[("1", "1")], res[("0", "1")], res[("1", "0")]
+    assert np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    gmax = float(a[1].abs().max())
+    assert float((a[1] - c[1]).abs().max()) <= 1e-4 * gmax and abs(a[0][0].sum() - c[0][0].sum()) <= 1e-5 * a[0][0].sum()

@@ -544,18 +544,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
         constexpr int HT = 9;                                  // taps (3x3), checked on the host
         const int W = p.Wi;
         const int R = BM + 2 * (W + 1);
-        // rows R, R + 1 = a 256-B zero REGION (R is even): a lane whose tap leaves the image reads it at its own
-        // (byte address & 255), i.e. on the banks its unmasked read would have used.  One zero row with a key of its own put
-        // a 17th address into a lane group whose 16 rows already cover all 64 banks: +1.4 LDS cycles on a 4-cycle
-        // ds_read_b128 at W = 26, +2.0..2.3 at W = 13 (tools/lds_sim.py; PMC: SQ_LDS_BANK_CONFLICT 30 % of the LDS cycles).
-        const int ZROW = R, DROW = R + 2;
-        const int ABUF = (R + 3) * 128;
+        const int ZROW = R, DROW = R + 1;
+        const int ABUF = (R + 2) * 128;
         char* Ah = As3;
         char* Bh = As3 + 2 * ABUF;
         const int nchunk = p.Ci / BK;
         const int64_t m0 = (int64_t)tile_m * BM;
         const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;       // == M in this geometry
-        if (tid < 32) *reinterpret_cast<f32x4*>(Ah + (tid >> 4) * ABUF + ZROW * 128 + (tid & 15) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < 16) *reinterpret_cast<f32x4*>(Ah + (tid >> 3) * ABUF + ZROW * 128 + (tid & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int NRB = M16 ? 2 * TM : TM;                 // operand row blocks per wave (16 or 32 rows each)
         constexpr int RBS = M16 ? 16 : 32;
         int jbase[NRB];                                      // filled in the prologue, under the first loads' latency
@@ -621,9 +617,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
             const int ro = __builtin_amdgcn_readlane(tap_ro, tap);
 #pragma unroll
             for (int b = 0; b < NRB; ++b) {
-                const int j = jbase[b] + ro;
-                const int a = j * 128 + ((f16x2_key<M16>(j) ^ lsel) << 4);
-                av[b] = abuf * ABUF + (((amask[b] >> tap) & 1u) ? a : ZROW * 128 + (a & 255));
+                const int j = ((amask[b] >> tap) & 1u) ? jbase[b] + ro : ZROW;
+                av[b] = abuf * ABUF + j * 128 + ((f16x2_key<M16>(j) ^ lsel) << 4);
             }
         };
         // ---- MFMA operand fragments, software-pipelined: a K-step never opens with exposed LDS latency.  The measured
@@ -1206,9 +1201,9 @@ const float* zero_page() {
 template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO = false>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s);
 
-// LDS bytes of the halo loop for a BM x BN tile on a map of width W: two halo buffers of BM + 2 (W + 1) rows (+ two zero
-// rows + sink row) and a ring of three weight stages, 128 B per row
-inline int64_t halo_lds_bytes(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 3) * 128 + 3ll * BN * 128; }
+// LDS bytes of the halo loop for a BM x BN tile on a map of width W: two halo buffers of BM + 2 (W + 1) rows (+ zero row
+// + sink row) and a ring of three weight stages, 128 B per row
+inline int64_t halo_lds_bytes(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 2) * 128 + 3ll * BN * 128; }
 
 // 3x3 stride-1 'same' geometry (forward, or the data gradient of such a conv), halo within the LDS and the 9 x 64-row
 // slots of the halo stream

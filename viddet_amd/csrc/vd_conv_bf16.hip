@@ -230,11 +230,6 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
         const int ABUF = (R + 2) * ROW_B;
         unsigned char* Ah = smem_b;                           // [2][R + 2][ROW_B]
         unsigned char* Bh = smem_b + 2 * ABUF;                // [2][BN][ROW_B]
-        // a 512-B zero region behind the weight stages, 256-B aligned: a lane whose tap leaves the image reads it at its own
-        // (byte address & 255), i.e. on the banks of its unmasked read.  The single zero row put a 17th address into a lane
-        // group whose 16 rows already cover all 64 banks (tools/lds_sim.py: +1.4 cycles per 4-cycle ds_read_b128 at W = 38).
-        const int ZOFF = (2 * ABUF + 2 * BN * ROW_B + 255) & ~255;
-        if (tid >= 32 && tid < 64) *reinterpret_cast<f32x4*>(smem_b + ZOFF + (tid - 32) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nchunk = p.Ci / KCH;
         const int64_t m0 = (int64_t)tile_m * BM;
         const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;
@@ -322,8 +317,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             const unsigned char* a[TM];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
-                const int ao = (cc & 1) * ABUF + (jbase[mi] + ro) * ROW_B + 16 * (lane >> 5);
-                a[mi] = smem_b + (((amask[mi] >> ct) & 1u) ? ao : ZOFF + (ao & 255));
+                const int j = ((amask[mi] >> ct) & 1u) ? jbase[mi] + ro : ZROW;
+                a[mi] = Ah + (cc & 1) * ABUF + j * ROW_B + 16 * (lane >> 5);
             }
             const unsigned char* b = Bh + wbuf * BN * ROW_B + (wn * TN * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
 #pragma unroll
@@ -549,7 +544,7 @@ const float* zero_page_b() {
 }
 
 // LDS bytes of the halo loop: two halo buffers of BM + 2 (W + 1) rows (+ zero row + sink row) and two weight stages
-inline int64_t halo_lds_b(int BM, int BN, int W) { return ((2ll * (BM + 2 * (W + 1) + 2) * ROW_B + 2ll * BN * ROW_B + 255) & ~255ll) + 512; }
+inline int64_t halo_lds_b(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 2) * ROW_B + 2ll * BN * ROW_B; }
 
 inline bool halo_ok_b(const vd_conv_desc& d, int BM, int BN) {
     if ((d.flags & VD_MATH_NOHALO) || d.T != 9 || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi || d.Ci % KCH)

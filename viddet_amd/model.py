@@ -108,9 +108,127 @@ class Program:
         return out
 
 
-_TUNE_CACHE = {}
-_PARITY_STREAMS = __import__('os').environ.get('VD_PARITY_STREAMS', '1') == '1'     # the four parity launches of a stride-2 data gradient on four streams (+1 % in same-box A/B)
-_FUSE_BWD_S2 = __import__('os').environ.get('VD_FUSE_BWD_S2', '1') == '1'   # A/B switch: fused BN-backward reductions in stride-2 data gradients
+class TuneCache(dict):
+    """The plan-time autotuner's choices (launch-record signature -> arithmetic / tile), persisted.
+
+    A choice made by timing differs between boxes and runs (launch-to-launch noise under the power limit is of the order
+    of the differences between tiles), and with it the summation order of every convolution: two runs of one seed were not
+    bit-identical, ranks of one job could disagree, and every process start paid the tuning again (38 of the 39.5 s of a
+    driver bench run).  So the table lives in a JSON file: `VD_TUNE_CACHE` (a path), default
+    viddet_amd/tune/gfx950_<hash>.json where <hash> identifies the kernel sources the choices were timed on (another
+    library build never reads them).  Read on first use, written (atomically, by rank 0) whenever a plan build added
+    entries; `VD_TUNE_CACHE=off` keeps it in memory only.  Under torch.distributed every rank adopts rank 0's choice for
+    a new entry (`agree`), so the ranks of a job run the same kernels."""
+
+    def __init__(self):
+        super().__init__()
+        self._loaded, self._dirty, self.tuned, self.hits = False, False, 0, 0
+
+    @staticmethod
+    def library_id():
+        import hashlib
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_common.h")] + \
+               [os.path.join(os.path.dirname(here), "include", "viddet_hip.h")]
+        h = hashlib.sha256()
+        if all(os.path.exists(f) for f in srcs):
+            for f in srcs:
+                h.update(open(f, "rb").read())
+        else:
+            h.update(open(L.LIB_PATH, "rb").read())
+        return h.hexdigest()[:12]
+
+    def path(self):
+        import os
+        p = os.environ.get("VD_TUNE_CACHE", "")
+        if p.lower() in ("off", "0", "none"):
+            return None
+        if p:
+            return p
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune", "gfx950_%s.json" % self.library_id())
+
+    def load(self):
+        import ast
+        import json
+        import os
+        self._loaded = True
+        p = self.path()
+        if p is None or not os.path.exists(p):
+            return
+        try:
+            doc = json.load(open(p))
+            if doc.get("library") not in (None, self.library_id()):
+                return                                   # timed on other kernels
+            for k, v in doc.get("entries", {}).items():
+                key = ast.literal_eval(k)
+                if not dict.__contains__(self, key):
+                    dict.__setitem__(self, key, tuple(v) if isinstance(v, list) else v)
+        except (OSError, ValueError, SyntaxError) as e:   # an unreadable table is a cold start, not an error
+            print("viddet_amd: ignoring tuning table %s (%s)" % (p, e), flush=True)
+
+    def __contains__(self, key):
+        if not self._loaded:
+            self.load()
+        hit = dict.__contains__(self, key)
+        self.hits += int(hit)
+        return hit
+
+    def __setitem__(self, key, value):
+        dict.__setitem__(self, key, value)
+        self._dirty = True
+        self.tuned += 1
+
+    def clear(self):
+        dict.clear(self)
+        self._loaded = False                             # entries on disk come back on the next lookup
+
+    def agree(self, best):
+        """rank 0's choice for a new entry, on every rank (all ranks build the same plans in the same order)."""
+        import os
+        if os.environ.get("VD_TUNE_AGREE", "1") == "0" or not torch.distributed.is_available() or \
+                not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+            return best
+        box = [best]
+        torch.distributed.broadcast_object_list(box, src=0)
+        return tuple(box[0]) if isinstance(box[0], list) else box[0]
+
+    def save(self):
+        import json
+        import os
+        if not self._dirty:
+            return
+        self._dirty = False
+        p = self.path()
+        if p is None:
+            return
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return
+        try:
+            os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
+            doc = {"library": self.library_id(), "device": "gfx950",
+                   "entries": {repr(k): (list(v) if isinstance(v, tuple) else v) for k, v in sorted(self.items(), key=lambda kv: repr(kv[0]))}}
+            tmp = "%s.%d.tmp" % (p, os.getpid())
+            with open(tmp, "w") as f:
+                json.dump(doc, f, indent=0)
+            os.replace(tmp, p)
+        except OSError as e:
+            print("viddet_amd: could not write tuning table %s (%s)" % (p, e), flush=True)
+
+
+_TUNE_CACHE = TuneCache()
+
+
+def _parity_streams():
+    """the four parity launches of a stride-2 data gradient on four streams (+1 % in same-box A/B); read when a plan is
+    built, so a test can build both forms in one process"""
+    return __import__('os').environ.get('VD_PARITY_STREAMS', '1') == '1'
+
+
+def _fuse_bwd_s2():
+    """A/B switch: fused BN-backward reductions in stride-2 data gradients (read at plan-build time)"""
+    return __import__('os').environ.get('VD_FUSE_BWD_S2', '1') == '1'
+
 
 
 def fp32_math():
@@ -193,7 +311,7 @@ def autotune_desc(d, reps=3):
     lib = L.load()
     s = L.stream_ptr()
     key = (math, d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.out_stride, base, bool(d.in_scale),
-           bool(d.stats_part), bool(d.amax_in and d.amax_w), bool(d.amax_out))
+           bool(d.stats_part), bool(d.amax_in and d.amax_w), bool(d.amax_out), d.Kfr, bool(d.bs_part))
     if key in _TUNE_CACHE:
         fl, d.tile = _TUNE_CACHE[key]
         d.flags = base | fl
@@ -221,6 +339,7 @@ def autotune_desc(d, reps=3):
         close = [fc for t, fc in ranked if t <= 1.04 * ranked[0][0]][:3]
         if len(close) > 1:
             best = min((time_of(fl, c, 3 * reps), (fl, c)) for fl, c in close)[1]
+    best = _TUNE_CACHE.agree(tuple(best))
     d.flags, d.tile = base | best[0], best[1]
     _TUNE_CACHE[key] = best
 
@@ -258,7 +377,7 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
                 print("wgrad tune %s flags %d: %.4f ms" % (key[1:11], fl, t / reps), flush=True)
             if best_t is None or t < best_t:
                 best, best_t = fl, t
-        _TUNE_CACHE[key] = best
+        _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
     d.flags = _TUNE_CACHE[key]
 
 
@@ -266,6 +385,7 @@ def autotune_program(prog, reps=3):
     for (fname, fn, args) in prog.recs:
         if fname == 'vd_conv_igemm':
             autotune_desc(args[0]._obj, reps)
+    _TUNE_CACHE.save()
 
 
 class Parameter:
@@ -1228,8 +1348,9 @@ class YOLOV3(object):
                                   flush=True)
                         if best_t is None or t < best_t:
                             best, best_t = (c, fl), t
-                _TUNE_CACHE[key] = best
+                _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
             d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
+        _TUNE_CACHE.save()
 
     # ------------------------------------------------------------------ inference
     def _in_shape(self, x):
@@ -1248,11 +1369,7 @@ class YOLOV3(object):
         if self.precision == 'bf16':
             key = ('infer_bf16', B, H, W)
             if key not in self._programs:
-                try:
-                    built = self._build_infer_bf16(B, H, W)
-                except torch.cuda.OutOfMemoryError:
-                    self._drop_plans()
-                    built = self._build_infer_bf16(B, H, W)
+                built = self._build_or_evict(lambda: self._build_infer_bf16(B, H, W))
                 self._refresh_bf16(built[3])
                 built[1]['packs_version'] = (self._weights_version, self._stats_version)
                 self._tune_bf16(built[0])
@@ -1266,11 +1383,7 @@ class YOLOV3(object):
         else:
             key = ('infer', B, H, W)
             if key not in self._programs:
-                try:
-                    self._programs[key] = self._build_infer(B, H, W)
-                except torch.cuda.OutOfMemoryError:
-                    self._drop_plans()
-                    self._programs[key] = self._build_infer(B, H, W)
+                self._programs[key] = self._build_or_evict(lambda: self._build_infer(B, H, W))
             prog, bufs, o = self._programs[key]
             self._refresh_fold()
         self._stage_inputs(bufs, x)
@@ -1733,13 +1846,13 @@ class YOLOV3(object):
             pm = producers.get(n.src)
             # the producer's BatchNorm-backward reductions ride in this data gradient's epilogue when it is the launch (or, for a
             # stride-2 conv, the four parity launches) that completes dy of the producer's output
-            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _FUSE_BWD_S2)) and
+            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _fuse_bwd_s2())) and
                             consumers[n.src][0] is n and pm.fr == n.fr) else None
             bs_rows = 0
             # the four parity launches of a stride-2 data gradient write disjoint pixels and read the same dz: run them
             # side by side on their own streams (VD_PARITY_STREAMS=1) so that they share dz in the L2s and fill each other's tails
             par = None
-            if _PARITY_STREAMS and len(plans) == 4 and self.overlap_wgrad:
+            if _parity_streams() and len(plans) == 4 and self.overlap_wgrad:
                 if getattr(self, '_par_streams', None) is None:
                     self._par_streams = [torch.cuda.Stream() for _ in range(3)]
                 par = self._par_streams
@@ -1796,6 +1909,7 @@ class YOLOV3(object):
         for sg in fwd + bwd:
             if isinstance(sg, Program):
                 autotune_program(sg)
+        _TUNE_CACHE.save()
         return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=dgrad_packs, ws=ws)
 
     @staticmethod
@@ -1877,17 +1991,24 @@ class YOLOV3(object):
         gc.collect()
         torch.cuda.empty_cache()
 
+    def _build_or_evict(self, build):
+        """Build a plan; when it does not fit beside the cached ones, drop those and build again.  The retry runs AFTER the
+        except block: inside it the live exception's traceback still holds the failed build's frame - its half-allocated
+        buffers - so empty_cache() could not return them and the second build needed room for one and a half plans."""
+        try:
+            return build()
+        except torch.cuda.OutOfMemoryError:
+            pass
+        self._drop_plans(keep=None)
+        return build()
+
     def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
         B, H, W = self._in_shape(x)
         key = ('train', B, H, W)
         if key not in self._programs:
             # every input shape owns its plan and buffers (random-shape training visits ten); when the next one does not
             # fit beside the others, drop those and build again - their kernel choices stay in the tuning cache
-            try:
-                self._programs[key] = self._build_train(B, H, W)
-            except torch.cuda.OutOfMemoryError:
-                self._drop_plans(keep=None)
-                self._programs[key] = self._build_train(B, H, W)
+            self._programs[key] = self._build_or_evict(lambda: self._build_train(B, H, W))
         tp = self._programs[key]
         f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         gt, obj, ctr, scl, wgt, cls = [f32(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
