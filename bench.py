@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, default=0, help="input side (default 416 train / 608 detect)")
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native", action="store_true", help="skip the VD_FP32_MATH=native sub-line of the training bench")
     ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = bf16 storage/MFMA inference (detect mode only)")
     ap.add_argument("--graphs", action="store_true", help="replay the inference program as a captured HIP graph")
@@ -59,11 +60,18 @@ def cpu_baseline(mode, size, classes):
     backend is the same library family (MKL-DNN)."""
     from oracle import torch_cpu as TC
     batch = 8 if mode == "train" else 8
-    fps, n, threads = TC.baseline(mode, size, classes, batch)
+    fps, n, threads = TC.baseline(mode, size, classes, batch, budget_s=14.0)
     what = "fwd + 4 losses + bwd + SGD-momentum" if mode == "train" else "fwd + decode + NMS"
-    return {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d step(s) of %d frames %dx%d, %s, fp32, torch-CPU operators (oneDNN) + the NumPy oracle's target merge / "
-                      "decode; not MXNet" % (n, batch, size, size, what)}
+    out = {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "%d step(s) of %d frames %dx%d, %s, fp32, torch-CPU operators (oneDNN) + the NumPy oracle's target merge / "
+                     "decode; not MXNet" % (n, batch, size, size, what)}
+    # the two configurations BASELINE.md section 3 names, a few seconds each (same port, same threads)
+    f0, n0, _ = TC.baseline("train", 416, 20, 4, budget_s=6.0)
+    f1, n1, _ = TC.baseline("detect", 608, 80, 1, budget_s=4.0)
+    out["baseline_md_configs"] = {
+        "configs0_voc_train_b4_416_fwd_bwd_sgd": {"value": round(f0, 3), "unit": "frames/s", "steps": n0},
+        "configs1_shape_detect_b1_608_fwd_decode_nms": {"value": round(f1, 3), "unit": "frames/s", "steps": n1}}
+    return out
 
 
 def main():
@@ -314,6 +322,33 @@ def main():
         if a.detail:
             with open(a.detail, "w") as f:
                 json.dump(detail, f, indent=0)
+
+    # ---- the strict reading of "fp32": the same step with every product on the fp32 MFMA (v_mfma_f32_32x32x2_f32, an exact
+    # fma chain; VD_FP32_MATH=native), a few steps, beside the headline - which runs the fp32-grade split arithmetics
+    if roof is not None and train and a.dtype == "f32" and world == 1 and not force_dist and K == 1 and not a.no_native \
+            and os.environ.get("VD_FP32_MATH", "auto") == "auto":
+        from viddet_amd.model import set_conv_math
+        del net
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        set_conv_math("native")
+        try:
+            net = yolo3_darknet53(classes)
+            net.initialize(init="he", seed=233, obj_bias=-4.0)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - t0) / 4
+            roof["native_fp32"] = {"frames_per_s": round(B / dtn, 2), "ms_per_step": round(dtn * 1e3, 3), "steps": 4,
+                                   "model_tflops": round(B / dtn * 197.3 / 1e3, 2) if (S == 416 and C == 80) else None,
+                                   "note": "VD_FP32_MATH=native: every conv product on v_mfma_f32_32x32x2_f32 (peak 157.3 TFLOP/s)"}
+        finally:
+            set_conv_math(None)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

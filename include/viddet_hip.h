@@ -65,6 +65,14 @@ extern "C" {
 
 const char* vd_last_error(void);
 int vd_version(void);
+/* The ABI's revision: bumped whenever an entry point's argument list or a descriptor's layout changes (round 2 added the
+ * amax_out / dhead_amax pointers in front of ws / stream and grew both descriptors: a caller built against the older
+ * header would have passed its stream handle as amax_out).  A binding checks vd_abi_version() == VD_ABI_VERSION and
+ * vd_sizeof_desc(i) == sizeof(its mirror of the descriptor) at load, before the first compute call: viddet_amd/lib.py
+ * does, INTEGRATION.md shows it.  i: 0 = vd_conv_desc, 1 = vd_wgrad_desc, 2 = vd_head_desc; unknown i -> -1. */
+#define VD_ABI_VERSION 3
+int vd_abi_version(void);
+int64_t vd_sizeof_desc(int which);
 
 /* ---------------------------------------------------------------------------------------
  * Generic tap-list implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).

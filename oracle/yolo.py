@@ -132,13 +132,18 @@ def prefetch_targets(img_h, img_w, grids, gt_boxes, gt_ids, num_class, gt_mixrat
     weights = np.zeros_like(center_t)
     objectness = np.zeros((b, tot, 9, 1))
     class_t = np.full((b, tot, 9, num_class), -1.0)                      # :83
-    gtx = (gt_boxes[..., 0] + gt_boxes[..., 2]) / 2.0
-    gty = (gt_boxes[..., 1] + gt_boxes[..., 3]) / 2.0
-    # BBoxCornerToCenter: w = x2-x1, x = x1 + w/2
+    # The generator receives fp32 NDArrays (transforms.py:258 mx.nd.array -> float32) and BBoxCornerToCenter runs on them
+    # (yolo_target.py:86-87): box coordinates are ROUNDED TO fp32 and width / height / centre are fp32 arithmetic
+    # (w = x2 - x1, x = x1 + w / 2).  The per-gt loop then works on NumPy scalars taken from .asnumpy() (:96-101) with
+    # Python ints, which NumPy 1.x promotes to float64 [UPSTREAM-UNVERIFIED: the NumPy of the MXNet 1.4-1.5 era; NEP 50 /
+    # NumPy 2 would keep float32], so the cell index int(gtx / orig_width * width) is a float64 quotient of an fp32
+    # centre.  A centre within fp32 rounding of a cell edge therefore lands where its ROUNDED value says.
+    gt_boxes = np.asarray(gt_boxes, dtype=np.float32)
     gtw = gt_boxes[..., 2] - gt_boxes[..., 0]
     gth = gt_boxes[..., 3] - gt_boxes[..., 1]
-    gtx = gt_boxes[..., 0] + gtw / 2.0
-    gty = gt_boxes[..., 1] + gth / 2.0
+    gtx = (gt_boxes[..., 0] + gtw / np.float32(2.0)).astype(np.float64)
+    gty = (gt_boxes[..., 1] + gth / np.float32(2.0)).astype(np.float64)
+    gtw, gth = gtw.astype(np.float64), gth.astype(np.float64)
     for bi in range(b):
         ious = _shape_iou(all_anchors, gtw[bi], gth[bi])                  # (9, M)
         matches = ious.argmax(axis=0)                                    # :94

@@ -24,6 +24,9 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
         assert name in L.SIGNATURES, "no ctypes signature for %s" % name
     assert set(L.SIGNATURES) == declared
     assert lib.vd_version() >= 100
+    assert lib.vd_abi_version() == L.ABI_VERSION == int(re.search(r"#define VD_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert [lib.vd_sizeof_desc(i) for i in range(4)] == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc),
+                                                         ctypes.sizeof(L.HeadDesc), -1]
     # struct sizes the Python side assumes (no compute call without a GPU)
     assert ctypes.sizeof(L.HeadDesc) == 136
     assert ctypes.sizeof(L.ConvDesc) % 8 == 0 and ctypes.sizeof(L.WgradDesc) % 8 == 0

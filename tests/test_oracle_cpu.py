@@ -166,6 +166,24 @@ def test_prefetch_targets_cell_border():
     assert np.allclose(ctr[0, p], [0.0, 0.0])
 
 
+def test_prefetch_targets_centre_within_fp32_rounding_of_a_cell_edge():
+    """The generator's inputs are fp32 NDArrays (transforms.py:258, yolo_target.py:86-87): x1 = 31.9999995 and
+    x2 = 95.9999995 ARE 32 and 96 there, the centre is 64 = the edge of stride-16 cells 3 | 4, and int(64 / 416 * 26) = 4.
+    In float64 the centre would be 63.9999995 -> cell 3.  Oracle and product both follow the fp32 boxes; y stays clear of
+    an edge (centre 104 -> 6.5 -> cell 6)."""
+    from viddet_amd.targets import prefetch_targets
+    size, grids, c = 416, [13, 26, 52], 2
+    gt = np.array([[[31.9999995, 59.0, 95.9999995, 149.0]]])          # 64 x 90 box: best shape-IoU (0.71) with anchor (59, 119) = stride 16, a = 2
+    assert np.float32(gt[0, 0, 0]) == 32.0 and np.float32(gt[0, 0, 2]) == 96.0
+    assert int(((gt[0, 0, 0] + gt[0, 0, 2]) / 2) / size * 26) == 3            # what float64 boxes would give
+    ids = np.zeros((1, 1, 1))
+    for obj, ctr, scl, wgt, cls in (Y.prefetch_targets(size, size, grids, gt, ids, c), prefetch_targets(size, size, gt, ids, c)):
+        p = int(np.nonzero(obj[0, :, 0])[0][0])
+        assert p == 3 * 13 * 13 + (6 * 26 + 4) * 3 + 2, p                     # stride-16 rows: cell y 6, cell x 4, anchor 2
+        assert np.allclose(ctr[0, p], [0.0, 0.5], atol=1e-7)
+        assert np.allclose(scl[0, p], [np.log(64 / 59), np.log(90 / 119)], atol=1e-6)
+
+
 def test_loss_ignore_and_masks():
     # one prediction row per case: positive, negative, ignored
     objness = np.array([[[0.3], [-0.2], [1.5]]])

@@ -323,3 +323,105 @@ def test_bf16_products_forward_and_gradients(tile):
         for got, r_ in ((dw.cpu().numpy(), dw_ref), (dev_nhwc_to_nchw(dx), dx_ref)):
             rel = float(np.sqrt(((got - r_) ** 2).mean()) / np.sqrt((r_ ** 2).mean()))
             assert 5e-4 < rel < 1e-2, rel
+
+
+def _errs(got, ref, S):
+    e = got - ref
+    return float(np.sqrt((e ** 2).mean())), float(np.abs(e).max()), float((np.abs(e) / np.maximum(S, 1e-300)).max())
+
+
+U = 2.0 ** -24          # fp32 unit round-off
+
+
+@pytest.mark.parametrize("mode", [True, "f16x2"])
+@pytest.mark.parametrize("ci,k", [(32, 1), (64, 1), (32, 3), (128, 1)])          # K = 32, 64, 288, 128
+def test_split_error_shallow_k(mode, ci, k):
+    """Shallow reductions (K = 32 .. 288: the 1x1 cells and first-stage 3x3s), where the fp32 fma chain makes ~1 ulp of
+    error and the split's per-product error (operand representation 2^-23 each + the dropped low x low term 2^-22) is
+    NOT averaged away by a long sum.  Measured here: rms and max error against fp64 and the largest error relative to
+    sum |a||b| (the quantity every fp32 dot-product error bound is stated in).  The claim: still fp32-grade - within the
+    a-priori bound of the arithmetic, 2^-21 sum |a||b| (+ the accumulation), which is below the gamma_K = K u bound ANY
+    fp32 summation order carries for K >= 8 - not 'never above the fma chain': at K = 32 the two are the same size."""
+    from viddet_amd import ops
+    n, h, w, co = 3, 26, 26, 128
+    rng, x, wt = _mk(n, ci, h, w, co, k, 500 + ci + k)
+    xd, wp = nchw_to_dev_nhwc(x), _packed(wt, co)
+    x32 = xd.permute(0, 3, 1, 2).double().cpu().numpy()
+    w32 = dev(wt).double().cpu().numpy()
+    ref = R.conv2d(x32, w32, 1, k // 2)
+    S = R.conv2d(np.abs(x32), np.abs(w32), 1, k // 2)
+    res = {}
+    for split in (False, mode):
+        out = torch.empty(n, h, w, co, device="cuda")
+        ops.conv_fwd(xd, wp, out, k=k, stride=1, pad=k // 2, Co=co, split=split)
+        torch.cuda.synchronize()
+        res[split] = _errs(dev_nhwc_to_nchw(out), ref, S)
+    K = ci * k * k
+    print("K = %4d  fp32 MFMA: rms %.2e max %.2e max/sum|ab| %.2f u   %s: rms %.2e max %.2e max/sum|ab| %.2f u" % (
+        (K,) + res[False][:2] + (res[False][2] / U, str(mode)) + res[mode][:2] + (res[mode][2] / U,)))
+    assert res[mode][2] <= 8 * U + K * U / 16, res            # a-priori: 2^-21 sum|a||b| = 8 u, + the accumulation's share
+    assert res[mode][2] <= max(1.25 * res[False][2], 8 * U)   # and never worse than the fma chain beyond that bound
+    assert res[mode][0] <= max(1.25 * res[False][0], 4 * U * float(np.sqrt((S ** 2).mean())))
+
+
+def test_split_error_on_operands_of_a_real_backward_pass():
+    """Operands captured from a real training step instead of Gaussians: the head gradients (dL/dlogit: mostly exact
+    zeros and sigmoid tails, a dynamic range far beyond 2^19) and the incoming gradient of a first-stage 3x3 conv, each
+    as the `dout` operand of its weight gradient (reduction over pixels) and as the activation operand of a 1x1 product
+    with the layer's channel count as K (the data gradient's shape: K = 96 / 64, shallow)."""
+    from viddet_amd import ops
+    from viddet_amd.model import ConvNode
+    from tests.test_model_gpu import _mk_net, _targets
+    c, size, B = 20, 128, 4
+    net, P = _mk_net(c, 61, obj_bias=-1.0)
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((B, 3, size, size)).astype(np.float32)
+    gt, tg = _targets(rng, B, c, size, 3)
+    net(dev(x), dev(gt), *[dev(t) for t in tg])
+    net.backward()
+    torch.cuda.synchronize()
+    bufs = net._last_train['bufs']
+    nodes = {n.name: n for n in net.nodes if isinstance(n, ConvNode)}
+    picks = [nodes["yolo_outputs.0.prediction"], nodes["yolo_outputs.2.prediction"], nodes["stages.0.2.body.1"]]
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for n in picks:
+        xin, dout = bufs[n.src].contiguous(), bufs['d:' + n.dst].contiguous()
+        co = dout.shape[-1]
+        amax, nz = float(dout.abs().max()), dout[dout != 0]
+        span = np.log2(amax / float(nz.abs().min())) if nz.numel() else 0.0
+        print("%s: dout %s  zeros %.1f %%  dynamic range 2^%.0f" % (n.name, tuple(dout.shape), 100.0 * (1 - nz.numel() / dout.numel()), span))
+        x32 = xin.permute(0, 3, 1, 2).double().cpu().numpy()
+        d32 = dout.permute(0, 3, 1, 2).double().cpu().numpy()
+        wz = np.zeros((co, n.cin, n.k, n.k))
+        # (1) weight gradient with the real (activation, gradient) pair
+        _, dw_ref = R.conv2d_backward(x32, wz, d32, 1, n.pad)
+        _, S = R.conv2d_backward(np.abs(x32), wz, np.abs(d32), 1, n.pad)
+        res = {}
+        for split in (False, True, "f16x2"):
+            dwp = torch.empty(co, n.k * n.k * n.cin, device="cuda")
+            ops.conv_wgrad(xin, dout, dwp, ws, k=n.k, stride=1, pad=n.pad, Co=co, split=split)
+            dw = torch.empty(co, n.cin, n.k, n.k, device="cuda")
+            ops.unpack_weight(dwp, dw)
+            torch.cuda.synchronize()
+            res[split] = _errs(dw.double().cpu().numpy(), dw_ref, S)
+        print("  wgrad     fp32 MFMA rms %.2e max %.2e | 3-way bf16 rms %.2e max %.2e | 2-way fp16 rms %.2e max %.2e" % (
+            res[False][:2] + res[True][:2] + res["f16x2"][:2]))
+        for m in (True, "f16x2"):
+            assert res[m][0] <= 1.25 * res[False][0] + 1e-9 * float(np.sqrt((dw_ref ** 2).mean())) + 1e-30, (n.name, m, res)
+            assert res[m][1] <= 2.0 * res[False][1] + 8 * U * float(S.max()), (n.name, m, res)
+        # (2) the gradient tensor as the activation operand of a shallow-K product (K = its channel count)
+        wt = rng.standard_normal((64, co, 1, 1)) * np.sqrt(1.0 / co)
+        w32 = dev(wt).double().cpu().numpy()
+        ref = R.conv2d(d32, w32, 1, 0)
+        S2 = R.conv2d(np.abs(d32), np.abs(w32), 1, 0)
+        wp = _packed(wt, 64)
+        for split in (False, True, "f16x2"):
+            out = torch.empty(dout.shape[0], dout.shape[1], dout.shape[2], 64, device="cuda")
+            ops.conv_fwd(dout, wp, out, k=1, stride=1, pad=0, Co=64, split=split)
+            torch.cuda.synchronize()
+            res[split] = _errs(dev_nhwc_to_nchw(out), ref, S2)
+        print("  K = %3d   fp32 MFMA rms %.2e max/sum|ab| %.2f u | 3-way bf16 rms %.2e %.2f u | 2-way fp16 rms %.2e %.2f u" % (
+            co, res[False][0], res[False][2] / U, res[True][0], res[True][2] / U, res["f16x2"][0], res["f16x2"][2] / U))
+        for m in (True, "f16x2"):
+            assert res[m][1] <= 2.0 * res[False][1] + 8 * U * float(S2.max()), (n.name, m, res)
+            assert res[m][0] <= 1.25 * res[False][0] + 4 * U * float(np.sqrt((S2 ** 2).mean())), (n.name, m, res)

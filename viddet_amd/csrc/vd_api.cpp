@@ -15,4 +15,13 @@ void vd_set_error(const char* fmt, ...) {
 extern "C" {
 const char* vd_last_error(void) { return g_err; }
 int vd_version(void) { return 100; }
+int vd_abi_version(void) { return VD_ABI_VERSION; }
+int64_t vd_sizeof_desc(int which) {
+    switch (which) {
+        case 0: return (int64_t)sizeof(vd_conv_desc);
+        case 1: return (int64_t)sizeof(vd_wgrad_desc);
+        case 2: return (int64_t)sizeof(vd_head_desc);
+        default: return -1;
+    }
+}
 }

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VD_LIB: developer override for A/B-testing a differently built kernel library (tools/ only)
 LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hip.so")
 
+ABI_VERSION = 3          # include/viddet_hip.h VD_ABI_VERSION
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
@@ -66,6 +67,8 @@ _i, _i64, _f, _d, _p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
 SIGNATURES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_version": (_i, []),
+    "vd_abi_version": (_i, []),
+    "vd_sizeof_desc": (_i64, [_i]),
     "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
     "vd_conv_igemm_mtiles": (_i, [C.POINTER(ConvDesc)]),
     "vd_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _i, _p]),
@@ -142,6 +145,15 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # the ABI revision and the descriptor layouts this binding was written against (include/viddet_hip.h VD_ABI_VERSION):
+    # a library built from another header revision would misread positional pointers - refuse before the first launch
+    if lib.vd_abi_version() != ABI_VERSION:
+        raise VidDetHipError("%s has ABI revision %d, this binding is written for %d: rebuild (make -C viddet_amd/csrc)"
+                             % (LIB_PATH, lib.vd_abi_version(), ABI_VERSION))
+    for i, st in enumerate((ConvDesc, WgradDesc, HeadDesc)):
+        if lib.vd_sizeof_desc(i) != C.sizeof(st):
+            raise VidDetHipError("%s: sizeof(%s) is %d in the library, %d in this binding" %
+                                 (LIB_PATH, st.__name__, lib.vd_sizeof_desc(i), C.sizeof(st)))
     _lib = lib
     return lib
 

@@ -18,7 +18,10 @@ def prefetch_targets(height, width, gt_boxes, gt_ids, num_class, gt_mixratio=Non
 
     Returns float32 arrays: objectness (B,P,1), center_targets (B,P,2), scale_targets (B,P,2),
     weights (B,P,2), class_targets (B,P,C)."""
-    gt_boxes = np.asarray(gt_boxes, dtype=np.float64)
+    # fp32 boxes and fp32 width / height / centre (the generator's inputs are fp32 NDArrays and BBoxCornerToCenter runs on
+    # them, yolo_target.py:86-87), float64 from there on (NumPy scalars in the per-gt loop, :96-133): a centre within fp32
+    # rounding of a cell edge goes to the cell its rounded value names
+    gt_boxes = np.asarray(gt_boxes, dtype=np.float32)
     gt_ids = np.asarray(gt_ids)
     B, M = gt_boxes.shape[:2]
     grids_h = [height // s for s in STRIDES[::-1]]
@@ -33,8 +36,9 @@ def prefetch_targets(height, width, gt_boxes, gt_ids, num_class, gt_mixratio=Non
     cls = np.full((B, P, num_class), -1.0, np.float32)
     gw = gt_boxes[..., 2] - gt_boxes[..., 0]
     gh = gt_boxes[..., 3] - gt_boxes[..., 1]
-    gx = gt_boxes[..., 0] + gw / 2.0
-    gy = gt_boxes[..., 1] + gh / 2.0
+    gx = (gt_boxes[..., 0] + gw / np.float32(2.0)).astype(np.float64)
+    gy = (gt_boxes[..., 1] + gh / np.float32(2.0)).astype(np.float64)
+    gw, gh = gw.astype(np.float64), gh.astype(np.float64)
     # zero-centred shape IoU of every gt against the 9 anchors (yolo_target.py:88-94)
     aw, ah = _OUT_ANCHORS[:, 0][None, None], _OUT_ANCHORS[:, 1][None, None]
     inter = np.maximum(0.0, np.minimum(aw, gw[..., None])) * np.maximum(0.0, np.minimum(ah, gh[..., None]))
