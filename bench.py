@@ -235,8 +235,31 @@ def main():
                     seg()
         else:
             prog = net._programs[("infer_bf16" if a.dtype == "bf16" else "infer", B, S, S)][0]
-            recs = prog.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16"})
-            recs = [("vd_conv_igemm", m, e0, e1) for (_, m, e0, e1) in recs]
+            recs = prog.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16", "vd_yolo_decode_filter", "vd_nms_topk"})
+            torch.cuda.synchronize()
+            # the HBM-bound tail of the detect path (north_star: achieved GB/s on the decode / NMS kernels): algorithmic
+            # bytes = the three fp32 head maps read once (B * sum(g^2) * ldh * 4; SURVEY 8d: 7.73 MB/frame at 608 / C = 80)
+            # + B * 100 * 6 * 4 written, at the calibrated pass fraction above
+            ldh = 32 * ((3 * (5 + C) + 31) // 32)
+            head_bytes = 4.0 * B * K * sum((S // st) ** 2 for st in (32, 16, 8)) * ldh
+            for f_, _, e0, e1 in recs:
+                if f_ in ("vd_yolo_decode_filter", "vd_nms_topk"):
+                    ms = e0.elapsed_time(e1)
+                    key = "decode_filter" if f_ == "vd_yolo_decode_filter" else "nms"
+                    extra[key] = {"ms": round(ms, 4)}
+                    if key == "decode_filter":
+                        extra[key].update(algorithmic_mb=round(head_bytes / 1e6, 2), gb_s=round(head_bytes / ms / 1e6, 1),
+                                          frac_of_hbm_peak=round(head_bytes / ms / 1e6 / 8000.0, 4))
+                    else:
+                        cand = float(net._programs[("infer_bf16" if a.dtype == "bf16" else "infer", B, S, S)][2]["counts"].float().sum())
+                        extra[key].update(candidates=int(cand), note="one workgroup per image: radix select of the top 400, "
+                                          "bitonic sort, 400 x 400 IoU bitmask, sweep; reads 8 B per candidate (%.2f MB) - "
+                                          "latency-bound, not an HBM kernel" % (8.0 * cand / 1e6))
+            if "decode_filter" in extra and "nms" in extra:
+                t = extra["decode_filter"]["ms"] + extra["nms"]["ms"]
+                extra["decode_plus_nms"] = {"ms": round(t, 4), "gb_s": round((head_bytes + B * K * 2400.0) / t / 1e6, 1),
+                                            "algorithmic_mb_per_frame": round((head_bytes / (B * K) + 2400.0) / 1e6, 3)}
+            recs = [("vd_conv_igemm", m, e0, e1) for (f_, m, e0, e1) in recs if f_ in ("vd_conv_igemm", "vd_conv_igemm_bf16")]
         torch.cuda.synchronize()
         # the stand-alone forward BatchNorm+LeakyReLU passes, and the part of them that belongs to cells whose output feeds
         # ONE convolution only (what fusing the pass into the consumer's gather could remove)

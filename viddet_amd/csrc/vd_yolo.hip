@@ -321,6 +321,13 @@ __device__ __forceinline__ float bce_logits(float x, float z) {
 
 constexpr int LOSS_MAX_GT = 256;
 
+// One wave per head row (one pixel: 3 anchors x (5 + C) logits).  The row is staged in LDS with 16-B loads, the three
+// anchors' boxes are decoded and matched against the gt boxes by 3 x 16 lanes (lane = anchor * 16 + gt index mod 16, a
+// 16-lane max), and the gradient row - padding included - leaves with 16-B stores: one pass over head, targets and
+// gradient.  (Round 2's form read and wrote 4 B per lane at unaligned anchor offsets and ran decode + the gt loop on
+// lanes 0..2 of every wave: 1.18 TB/s.)  VEC = 16-B accesses (ldh % 4 == 0, 16-B aligned tensors: every plan of the
+// network); the scalar form stays for odd pitches.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const float* __restrict__ gt, int M,
                                                    const float* __restrict__ obj_t,
                                                    const float* __restrict__ center_t,
@@ -336,8 +343,9 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int C = h.C, npred = 5 + C, A = 3 * npred;
-    float* row = smem + wave * (A + 32);
-    float* aux = row + A;   // [3][8]: 5 grads, mask flag, objness
+    const int RW = (A + 3) & ~3;                       // staged row, a whole number of float4s (<= ldh when VEC)
+    float* row = smem + wave * (RW + 32);
+    float* aux = row + RW;  // [3][8]: 5 grads, mask flag, objness
     const int R0 = h.g[0] * h.g[0], R1 = h.g[1] * h.g[1], R2 = h.g[2] * h.g[2];
     const int R = R0 + R1 + R2, P = 3 * R;
     for (int i = threadIdx.x; i < M * 4; i += blockDim.x) sgt[i] = gt[(int64_t)b * M * 4 + i];
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
     float l_obj = 0.f, l_ctr = 0.f, l_scl = 0.f, l_cls = 0.f;
     float amx0 = 0.f, amx1 = 0.f, amx2 = 0.f;   // max-abs of the gradients this lane writes, per scale
     const float sw = fminf(1.0f / (float)C, 1.0f / 40.0f);
+    const int la = lane >> 4, lm = lane & 15;   // anchor / gt slot of this lane in the matching phase
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         int s, pix, pbase;
         if (r < R0) { s = 0; pix = r; pbase = 0; }
@@ -354,81 +363,104 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
         const int64_t hoff = ((int64_t)b * g * g + pix) * h.ldh;
         const float* src = h.head[s] + hoff;
         float* dst = (s == 0 ? dh0 : (s == 1 ? dh1 : dh2)) + hoff;
-        for (int e = lane; e < A; e += 64) row[e] = src[e];
+        if (VEC) {
+            for (int e = 4 * lane; e < RW; e += 256) *reinterpret_cast<f32x4*>(row + e) = *reinterpret_cast<const f32x4*>(src + e);
+        } else {
+            for (int e = lane; e < A; e += 64) row[e] = src[e];
+        }
         WAVE_SYNC();
-        if (lane < 3) {
-            const int a = lane;
+        if (la < 3) {
+            const int a = la;
             const float* raw = row + a * npred;
             const int64_t p = (int64_t)b * P + pbase + pix * 3 + a;
             const Box bb = decode_box(raw, pix % g, pix / g, h.stride[s], h.anchors[s][2 * a], h.anchors[s][2 * a + 1]);
-            if (box_out) {
-                box_out[p * 4 + 0] = bb.x1; box_out[p * 4 + 1] = bb.y1;
-                box_out[p * 4 + 2] = bb.x2; box_out[p * 4 + 3] = bb.y2;
-            }
-            // yolo_target.py:202-204 + gluoncv BBoxBatchIOU (offset 0, eps 1e-15, clip at 6.5504e4)
-            float ioumax = 0.f;
+            // yolo_target.py:202-204 + gluoncv BBoxBatchIOU (offset 0, eps 1e-15, clip at 6.5504e4): this lane's share of
+            // the gt boxes, then the maximum over the anchor's 16 lanes (an IoU is never negative: -1 = "none seen")
+            float ioumax = -1.f;
             const float parea = (bb.x2 - bb.x1) * (bb.y2 - bb.y1);
-            for (int m = 0; m < M; ++m) {
+            for (int m = lm; m < M; m += 16) {
                 const float gx1 = sgt[m * 4], gy1 = sgt[m * 4 + 1], gx2 = sgt[m * 4 + 2], gy2 = sgt[m * 4 + 3];
                 const float iw = fminf(fmaxf(fminf(bb.x2, gx2) - fmaxf(bb.x1, gx1), 0.f), 6.5504e4f);
                 const float ih = fminf(fmaxf(fminf(bb.y2, gy2) - fmaxf(bb.y1, gy1), 0.f), 6.5504e4f);
                 const float inter = iw * ih;
                 const float iou = inter / (parea + (gx2 - gx1) * (gy2 - gy1) - inter + 1e-15f);
-                ioumax = (m == 0) ? iou : fmaxf(ioumax, iou);
+                ioumax = fmaxf(ioumax, iou);
             }
-            const float dyn = (M > 0 && ioumax > ignore_thresh) ? -1.f : 0.f;
-            const float of = obj_t[p];
-            const bool mask = of > 0.f;                                 // yolo_target.py:264
-            const float objness = mask ? of : dyn;
-            // YOLOV3Loss
-            const float hard = objness > 0.f ? 1.f : objness;
-            const float omask = objness > 0.f ? objness : (objness >= 0.f ? 1.f : 0.f);
-            const float xo = raw[4];
-            l_obj += bce_logits(xo, hard) * omask;
-            aux[a * 8 + 4] = (vd_sigmoid(xo) - hard) * omask;
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-            if (mask) {
-                const float w0 = weight_t[p * 2] * objness, w1 = weight_t[p * 2 + 1] * objness;
-                const float c0 = center_t[p * 2], c1 = center_t[p * 2 + 1];
-                const float s0 = scale_t[p * 2], s1 = scale_t[p * 2 + 1];
-                l_ctr += bce_logits(raw[0], c0) * w0 + bce_logits(raw[1], c1) * w1;
-                g0 = (vd_sigmoid(raw[0]) - c0) * w0;
-                g1 = (vd_sigmoid(raw[1]) - c1) * w1;
-                const float d2 = raw[2] - s0, d3 = raw[3] - s1;
-                l_scl += fabsf(d2) * w0 + fabsf(d3) * w1;
-                g2 = (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f)) * w0;
-                g3 = (d3 > 0.f ? 1.f : (d3 < 0.f ? -1.f : 0.f)) * w1;
+            ioumax = fmaxf(ioumax, __shfl_xor(ioumax, 1));
+            ioumax = fmaxf(ioumax, __shfl_xor(ioumax, 2));
+            ioumax = fmaxf(ioumax, __shfl_xor(ioumax, 4));
+            ioumax = fmaxf(ioumax, __shfl_xor(ioumax, 8));
+            if (lm == 0) {
+                if (box_out) {
+                    box_out[p * 4 + 0] = bb.x1; box_out[p * 4 + 1] = bb.y1;
+                    box_out[p * 4 + 2] = bb.x2; box_out[p * 4 + 3] = bb.y2;
+                }
+                const float dyn = (M > 0 && ioumax > ignore_thresh) ? -1.f : 0.f;
+                const float of = obj_t[p];
+                const bool mask = of > 0.f;                                 // yolo_target.py:264
+                const float objness = mask ? of : dyn;
+                // YOLOV3Loss
+                const float hard = objness > 0.f ? 1.f : objness;
+                const float omask = objness > 0.f ? objness : (objness >= 0.f ? 1.f : 0.f);
+                const float xo = raw[4];
+                l_obj += bce_logits(xo, hard) * omask;
+                aux[a * 8 + 4] = (vd_sigmoid(xo) - hard) * omask;
+                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+                if (mask) {
+                    const float w0 = weight_t[p * 2] * objness, w1 = weight_t[p * 2 + 1] * objness;
+                    const float c0 = center_t[p * 2], c1 = center_t[p * 2 + 1];
+                    const float s0 = scale_t[p * 2], s1 = scale_t[p * 2 + 1];
+                    l_ctr += bce_logits(raw[0], c0) * w0 + bce_logits(raw[1], c1) * w1;
+                    g0 = (vd_sigmoid(raw[0]) - c0) * w0;
+                    g1 = (vd_sigmoid(raw[1]) - c1) * w1;
+                    const float d2 = raw[2] - s0, d3 = raw[3] - s1;
+                    l_scl += fabsf(d2) * w0 + fabsf(d3) * w1;
+                    g2 = (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f)) * w0;
+                    g3 = (d3 > 0.f ? 1.f : (d3 < 0.f ? -1.f : 0.f)) * w1;
+                }
+                aux[a * 8 + 0] = g0; aux[a * 8 + 1] = g1; aux[a * 8 + 2] = g2; aux[a * 8 + 3] = g3;
+                aux[a * 8 + 5] = mask ? 1.f : 0.f;
+                aux[a * 8 + 6] = objness;
             }
-            aux[a * 8 + 0] = g0; aux[a * 8 + 1] = g1; aux[a * 8 + 2] = g2; aux[a * 8 + 3] = g3;
-            aux[a * 8 + 5] = mask ? 1.f : 0.f;
-            aux[a * 8 + 6] = objness;
         }
         WAVE_SYNC();
         float amx_r = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            const bool mask = aux[a * 8 + 5] > 0.f;
+        // gradient of element e = a * npred + j of the row (0 beyond A: the padding channels)
+        auto grad_of = [&](int e) -> float {
+            if (e >= A) return 0.f;
+            const int a = e >= 2 * npred ? 2 : (e >= npred ? 1 : 0);
+            const int j = e - a * npred;
+            if (j < 5) return aux[a * 8 + j];
+            if (!(aux[a * 8 + 5] > 0.f)) return 0.f;
             const float objness = aux[a * 8 + 6];
             const int64_t p = (int64_t)b * P + pbase + pix * 3 + a;
-            for (int j = lane; j < npred; j += 64) {
-                float gv;
-                if (j < 5) gv = aux[a * 8 + j];
-                else if (!mask) gv = 0.f;
-                else {
-                    float t = class_t[p * C + (j - 5)];
-                    if (label_smooth) {                                   // yolo_target.py:271-278
-                        if (t > 0.5f) t -= sw;
-                        if (!(t < -0.5f || t > 0.5f)) t = sw;
-                    }
-                    const float cm = (t >= 0.f ? 1.f : 0.f) * objness;    // class_mask * objness_t
-                    const float x = row[a * npred + j];
-                    l_cls += bce_logits(x, t) * cm;
-                    gv = (vd_sigmoid(x) - t) * cm;
+            float t = class_t[p * C + (j - 5)];
+            if (label_smooth) {                                   // yolo_target.py:271-278
+                if (t > 0.5f) t -= sw;
+                if (!(t < -0.5f || t > 0.5f)) t = sw;
+            }
+            const float cm = (t >= 0.f ? 1.f : 0.f) * objness;    // class_mask * objness_t
+            const float x = row[e];
+            l_cls += bce_logits(x, t) * cm;
+            return (vd_sigmoid(x) - t) * cm;
+        };
+        if (VEC) {
+            for (int e = 4 * lane; e < h.ldh; e += 256) {
+                f32x4 gv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gv[q] = grad_of(e + q);
+                    amx_r = fmaxf(amx_r, fabsf(gv[q]));
                 }
-                dst[a * npred + j] = gv;
+                *reinterpret_cast<f32x4*>(dst + e) = gv;
+            }
+        } else {
+            for (int e = lane; e < h.ldh; e += 64) {
+                const float gv = grad_of(e);
+                dst[e] = gv;
                 amx_r = fmaxf(amx_r, fabsf(gv));
             }
         }
-        for (int e = A + lane; e < h.ldh; e += 64) dst[e] = 0.f;
         if (s == 0) amx0 = fmaxf(amx0, amx_r);
         else if (s == 1) amx1 = fmaxf(amx1, amx_r);
         else amx2 = fmaxf(amx2, amx_r);
@@ -546,10 +578,15 @@ int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const fl
         return VD_EWORKSPACE;
     }
     const int A = 3 * (5 + h->C);
-    const int lds = 4 * (A + 32) * (int)sizeof(float);
+    const int lds = 4 * (((A + 3) & ~3) + 32) * (int)sizeof(float);
     VD_REQUIRE(lds <= 48 * 1024, "vd_yolo_loss_fwd_bwd: too many classes for the LDS row stage");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_yolo_loss, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t,
+    // 16-B accesses when every head / gradient row starts 16-B aligned and holds a whole number of float4s
+    uintptr_t al = 0;
+    for (int i = 0; i < 3; ++i) al |= (uintptr_t)h->head[i] | (uintptr_t)dhead[i];
+    const bool vec = (h->ldh % 4 == 0) && (al % 16 == 0);
+    auto kfn = vec ? k_yolo_loss<true> : k_yolo_loss<false>;
+    hipLaunchKernelGGL(kfn, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t,
                        class_t, ignore_thresh, label_smooth, dhead[0], dhead[1], dhead[2], box_out, (float*)ws,
                        dhead_amax ? dhead_amax[0] : nullptr, dhead_amax ? dhead_amax[1] : nullptr,
                        dhead_amax ? dhead_amax[2] : nullptr);
