@@ -59,6 +59,10 @@ extern "C" {
 /* with VD_MATH_F16X2: keep the generic K loop where the library would stage the activation operand as a pixel halo tile
  * (3x3 stride-1 convs and their data gradients; vd_conv.hip, HALO) - for A/B timing by the host autotuner */
 #define VD_MATH_NOHALO   128
+/* VD_STORE_BF16 (vd_wgrad_desc.flags): `in` and `dout` are bf16 tensors (bf16-storage training, BASELINE configs[4]): the
+ * products are the one-term bf16 MFMA of VD_MATH_BF16 on operands that are ALREADY bf16, the weight gradient stays fp32.
+ * The forward / data-gradient convs of that mode are vd_conv_igemm_bf16. */
+#define VD_STORE_BF16    256
 #define VD_AMAX_SLOTS    32
 #define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
 #define VD_AMAX_FLOATS   (VD_AMAX_SLOTS * VD_AMAX_STRIDE)   /* floats per tensor */
@@ -70,7 +74,7 @@ int vd_version(void);
  * header would have passed its stream handle as amax_out).  A binding checks vd_abi_version() == VD_ABI_VERSION and
  * vd_sizeof_desc(i) == sizeof(its mirror of the descriptor) at load, before the first compute call: viddet_amd/lib.py
  * does, INTEGRATION.md shows it.  i: 0 = vd_conv_desc, 1 = vd_wgrad_desc, 2 = vd_head_desc; unknown i -> -1. */
-#define VD_ABI_VERSION 3
+#define VD_ABI_VERSION 4
 int vd_abi_version(void);
 int64_t vd_sizeof_desc(int which);
 
@@ -143,9 +147,12 @@ int vd_conv_igemm_mtiles(const vd_conv_desc* d);
  * in / wp / residual are bf16 (NHWC with Ci % 64 == 0, or Ci == 32 unpadded: a K-step then holds two taps;
  * weights [Co][T*Ci]), accumulation and epilogue fp32,
  * out is bf16 (out_f32 = 0) or fp32 (out_f32 = 1: prediction heads, shared decode / NMS kernels).
- * Forward geometry only (out_stride 1).  d->tile: 0 = default, 1..13 = tile variant (256x256 .. 128x64; the
- * host autotunes it). */
+ * Any output geometry of vd_conv_igemm (the strided / offset outputs of the stride-2 data gradients included) and, for
+ * bf16-storage training, d->stats_part: the fused BatchNorm statistics of the raw outputs, taken from the fp32
+ * accumulators before they are rounded to bf16 - [vd_conv_igemm_bf16_mtiles(d)][2 * Co] floats, as vd_conv_igemm writes
+ * them.  d->tile: 0 = default, 1..13 = tile variant (256x256 .. 128x64; the host autotunes it). */
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
+int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d);
 /* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T,
                         void* stream);
@@ -353,6 +360,35 @@ int64_t vd_yolo_loss_ws_bytes(const vd_head_desc* h);
  * ------------------------------------------------------------------------------------- */
 int vd_sgd_momentum(float* w, const float* grad, float* mom, int64_t n,
                     float lr, float momentum, float wd, float rescale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * bf16-STORAGE training (BASELINE configs[4]: "combined-dataset training ... bf16"; the reference is fp32-only,
+ * train_yolov3.py:623-636, so this mode is judged against the fp32 oracle at a stated bf16 tolerance).
+ * Activations (conv outputs z, cell outputs y) and their gradients (dy, dz) are bf16 NHWC tensors; weights (fp32 master +
+ * bf16 images), weight gradients, BatchNorm vectors / statistics, the head logits, the losses and the optimiser stay fp32.
+ *   convs fwd / dgrad      vd_conv_igemm_bf16 (stats_part; strided outputs)
+ *   weight gradients       vd_conv_wgrad with VD_STORE_BF16 in vd_wgrad_desc.flags; vd_stem_wgrad_bf16
+ *   BatchNorm passes       the entry points below: the fp32 kernels instantiated on bf16 tensors (fp32 arithmetic)
+ *   concat                 vd_upsample2x_concat on half the channel counts (a copy); vd_upsample2x_concat_bwd_bf16
+ *   loss                   vd_yolo_loss_fwd_bwd_bf16: fp32 logits in, bf16 gradient rows out
+ * ------------------------------------------------------------------------------------- */
+int vd_bn_stats_bf16(const void* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes, void* stream);
+int vd_bn_apply_leaky_bf16(const void* x, const float* scale, const float* shift, const void* residual, void* y,
+                           int64_t M, int C, float slope, void* stream);
+int vd_bn_bwd_reduce_bf16(const void* x, const void* dy, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_invstd, int64_t M, int C, float slope, double* sums2, void* ws, int64_t ws_bytes,
+                          void* stream);
+int vd_bn_bwd_apply_bf16(const void* x, const void* dy, const float* scale, const float* shift, const float* save_mean,
+                         const float* save_invstd, const double* sums2, double count, int64_t M, int C, float slope,
+                         void* dx, void* stream);
+int vd_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int vd_upsample2x_concat_bwd_bf16(const void* dout, void* dup, void* droute, int N, int Ho, int Wo, int Cu, int Cr, void* stream);
+int vd_stem_wgrad_bf16(const float* x_nchw, const void* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
+                       void* stream);
+int vd_yolo_loss_fwd_bwd_bf16(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
+                              const float* scale_t, const float* weight_t, const float* class_t, float ignore_thresh,
+                              int label_smooth, float* losses, void* const dhead[3], float* box_out, void* ws, int64_t ws_bytes,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,208 @@
+"""GPU: the kernels of bf16-STORAGE training (BASELINE configs[4]; include/viddet_hip.h, last section), one by one.
+The reference is fp32-only (train_yolov3.py:623-636), so every bound here is defined against the fp64 oracle on operands
+that are exactly bf16-representable: a product of two bf16 values is exact in fp32 and the kernels accumulate in fp32, so a
+convolution differs from the oracle by fp32 summation error plus ONE rounding of its output to bf16 (2^-9 relative); the
+streaming kernels do fp32 arithmetic on the widened values and round once."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as R
+from oracle import yolo as Y
+from tests.util import dev, maxdiff
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPS = 2.0 ** -8          # bf16 round-to-nearest: relative error <= 2^-9; bounds below use 2^-8
+
+
+def _r(a):
+    """round to bf16, return float64"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(BF).float().numpy().astype(np.float64)
+
+
+def _nhwc_b(a):
+    return torch.from_numpy(np.moveaxis(a, 1, -1).copy()).to(BF).cuda()
+
+
+def _nchw(t):
+    return np.moveaxis(t.float().cpu().numpy().astype(np.float64), -1, 1)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 18, 20, 128, 3, 2, 1), (2, 32, 18, 20, 64, 3, 2, 1), (3, 64, 13, 13, 128, 3, 1, 1),
+                                   (2, 128, 9, 11, 64, 1, 1, 0), (2, 64, 16, 16, 32, 3, 1, 1)])     # n, ci, h, w, co, k, stride, pad
+def test_data_gradient_through_the_bf16_conv_kernel(shape):
+    """dX of a conv from bf16 dZ: the tap plans of ops.dgrad_plans through vd_conv_igemm_bf16 - for stride 2 four parity
+    launches with strided / offset outputs - with in-place accumulation onto an existing bf16 gradient (residual)."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = shape
+    rng = np.random.default_rng(sum(shape))
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    x = rng.standard_normal((n, ci, h, w))
+    wt = _r(rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k))
+    dz = _r(rng.standard_normal((n, co, ho, wo)))
+    skip = _r(rng.standard_normal((n, ci, h, w)))
+    dx_ref, _ = R.conv2d_backward(x, wt, dz, s, p)
+    ref = dx_ref + skip
+    dzd, skd = _nhwc_b(dz), _nhwc_b(skip)
+    wp32 = torch.empty(co, k * k * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp32, co)
+    out = torch.zeros(n, h, w, ci, dtype=BF, device="cuda")
+    for pl in ops.dgrad_plans(k, p, s, h, w):
+        T = len(pl["taps"])
+        wpk = torch.empty(ci, T * co, device="cuda")
+        ops.pack_weight_dgrad(wp32, wpk, Co=co, Co_pad=co, Ci=ci, kd=1, kh=k, kw=k, tap_ids=pl["tap_ids"], src_packed=True)
+        wb = torch.empty(ci, T * co, dtype=BF, device="cuda")
+        ops.pack_weight_bf16(wpk, wb, Co=ci, Co_pad=ci, Ci=co, Ci_pad=co, T=T)
+        ops.conv_igemm_bf16(dzd, wb, out, N=n, Hi=ho, Wi=wo, Ci=co, Hg=pl["Hg"], Wg=pl["Wg"], in_stride=1, taps=pl["taps"],
+                            Ho=h, Wo=w, Co=ci, ldo=ci, out_stride=s, out_oy=pl["py"], out_ox=pl["px"], residual=skd, ldr=ci)
+    torch.cuda.synchronize()
+    got = _nchw(out)
+    tol = 2e-4 + np.abs(ref).max() * EPS
+    assert maxdiff(got, ref) < tol, (maxdiff(got, ref), tol)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 6, 10, 13])
+def test_forward_conv_with_fused_statistics(tile):
+    """Training forward: raw bf16 output + the BatchNorm partial sums of the fp32 accumulators (one table row per M tile),
+    finished by vd_bn_sum_partials: sum and sum of squares of the UNROUNDED conv output."""
+    from viddet_amd import ops
+    n, ci, h, w, co, k = 3, 64, 15, 13, 64 if tile in (10, 13) else 128, 3
+    rng = np.random.default_rng(400 + tile)
+    x = _r(rng.standard_normal((n, ci, h, w)))
+    wt = _r(rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k))
+    z = R.conv2d(x, wt, 1, 1)
+    wp32 = torch.empty(co, k * k * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp32, co)
+    wb = torch.empty(co, k * k * ci, dtype=BF, device="cuda")
+    ops.pack_weight_bf16(wp32, wb, Co=co, Co_pad=co, Ci=ci, Ci_pad=ci, T=k * k)
+    mt = ops.conv_bf16_mtiles(n, h, w, ci, co, tile)
+    part = torch.full((mt, 2 * co), 7.0, device="cuda")
+    out = torch.empty(n, h, w, co, dtype=BF, device="cuda")
+    ops.conv_igemm_bf16(_nhwc_b(x), wb, out, N=n, Hi=h, Wi=w, Ci=ci, Hg=h, Wg=w, in_stride=1, taps=ops.fwd_taps(k, 1), Ho=h, Wo=w,
+                        Co=co, ldo=co, tile=tile, stats_part=part)
+    torch.cuda.synchronize()
+    assert maxdiff(_nchw(out), z) < 2e-4 + np.abs(z).max() * EPS
+    sums = part.double().sum(dim=0).cpu().numpy()
+    assert np.allclose(sums[:co], z.sum(axis=(0, 2, 3)), atol=2e-3) and np.allclose(sums[co:], (z ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 13, 13, 256, 3, 1, 1), (2, 128, 9, 11, 128, 1, 1, 0), (2, 64, 18, 20, 64, 3, 2, 1),
+                                   (2, 64, 16, 16, 32, 1, 1, 0), (3, 32, 12, 12, 64, 3, 1, 1)])
+def test_weight_gradient_from_bf16_operands(shape):
+    from viddet_amd import ops
+    n, ci, h, w, co, k, s, p = shape
+    rng = np.random.default_rng(sum(shape) + 7)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    x = _r(rng.standard_normal((n, ci, h, w)))
+    dz = _r(rng.standard_normal((n, co, ho, wo)))
+    _, dw_ref = R.conv2d_backward(x, np.zeros((co, ci, k, k)), dz, s, p)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    dwp = torch.full((co, k * k * ci), 3.0, device="cuda")
+    ops.conv_wgrad(_nhwc_b(x), _nhwc_b(dz), dwp, ws, k=k, stride=s, pad=p, Co=co)
+    dw = torch.empty(co, ci, k, k, device="cuda")
+    ops.unpack_weight(dwp, dw)
+    torch.cuda.synchronize()
+    assert maxdiff(dw.cpu().numpy(), dw_ref) < 2e-4 * np.sqrt(n * ho * wo)       # exact products, fp32 sums: no bf16 term
+
+
+def test_batchnorm_passes_on_bf16_tensors():
+    """apply (+ residual), backward reductions, backward apply: fp32 arithmetic on the widened bf16 values, one rounding
+    of the result - against the fp64 formulas on the same bf16 inputs."""
+    from viddet_amd import ops
+    M, Cc = 3 * 17 * 19, 96
+    rng = np.random.default_rng(12)
+    z, res, dy = [_r(rng.standard_normal((M, Cc)) * s_) for s_ in (2.0, 1.0, 0.7)]
+    scale, shift = rng.uniform(0.5, 1.5, Cc), rng.standard_normal(Cc)
+    mean, invstd = rng.standard_normal(Cc) * 0.1, rng.uniform(0.5, 2.0, Cc)
+    b = lambda a: torch.from_numpy(a.astype(np.float32)).to(BF).cuda()
+    zd, rd, dyd = b(z), b(res), b(dy)
+    sc, sh, mu, iv = dev(scale), dev(shift), dev(mean), dev(invstd)
+    y = torch.empty(M, Cc, dtype=BF, device="cuda")
+    ops.bn_apply_leaky(zd, sc, sh, rd, y, M, Cc)
+    u = z * scale + shift
+    ref = np.where(u > 0, u, 0.1 * u) + res
+    torch.cuda.synchronize()
+    assert maxdiff(y.float().cpu().numpy(), ref) < 1e-5 + np.abs(ref).max() * EPS
+    # statistics of a bf16 tensor (the head-bias gradient: column sums of the bf16 dhead)
+    ws = torch.empty(max(ops.bn_stats_ws_bytes(M, Cc), 16), dtype=torch.uint8, device="cuda")
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device="cuda")
+    ops.bn_stats(M, Cc, dyd, sums, ws)
+    torch.cuda.synchronize()
+    assert np.allclose(sums.cpu().numpy(), np.concatenate([dy.sum(0), (dy ** 2).sum(0)]), rtol=1e-5, atol=1e-3)
+    # backward reductions
+    sums2 = torch.empty(2 * Cc, dtype=torch.float64, device="cuda")
+    ops.bn_bwd_reduce(zd, dyd, sc, sh, mu, iv, M, Cc, sums2, ws)
+    g = np.where(u > 0, dy, 0.1 * dy)
+    xh = (z - mean) * invstd
+    torch.cuda.synchronize()
+    assert np.allclose(sums2.cpu().numpy(), np.concatenate([g.sum(0), (g * xh).sum(0)]), rtol=1e-4, atol=2e-3)
+    dx = torch.empty(M, Cc, dtype=BF, device="cuda")
+    s2 = torch.from_numpy(np.concatenate([g.sum(0), (g * xh).sum(0)])).cuda()
+    ops.bn_bwd_apply(zd, dyd, sc, sh, mu, iv, s2, float(M), M, Cc, dx)
+    refd = scale * (g - g.sum(0) / M - xh * (g * xh).sum(0) / M)
+    torch.cuda.synchronize()
+    assert maxdiff(dx.float().cpu().numpy(), refd) < 1e-5 + np.abs(refd).max() * EPS
+
+
+def test_concat_and_add_on_bf16_tensors():
+    from viddet_amd import ops
+    n, hu, wu, cu, cr = 2, 5, 7, 64, 128
+    rng = np.random.default_rng(3)
+    up, route = _r(rng.standard_normal((n, hu, wu, cu))), _r(rng.standard_normal((n, 2 * hu, 2 * wu, cr)))
+    b = lambda a: torch.from_numpy(a.astype(np.float32)).to(BF).cuda()
+    out = torch.empty(n, 2 * hu, 2 * wu, cu + cr, dtype=BF, device="cuda")
+    ops.upsample2x_concat(b(up), b(route), out)
+    ref = np.concatenate([up.repeat(2, axis=1).repeat(2, axis=2), route], axis=-1)
+    torch.cuda.synchronize()
+    assert maxdiff(out.float().cpu().numpy(), ref) == 0.0                      # a copy
+    dout = _r(rng.standard_normal(ref.shape))
+    dup, drt = torch.empty(n, hu, wu, cu, dtype=BF, device="cuda"), torch.empty(n, 2 * hu, 2 * wu, cr, dtype=BF, device="cuda")
+    ops.upsample2x_concat_bwd(b(dout), dup, drt)
+    r_up = dout[..., :cu].reshape(n, hu, 2, wu, 2, cu).sum(axis=(2, 4))
+    torch.cuda.synchronize()
+    assert maxdiff(drt.float().cpu().numpy(), dout[..., cu:]) == 0.0
+    assert maxdiff(dup.float().cpu().numpy(), r_up) < np.abs(r_up).max() * EPS
+    a_, b_ = _r(rng.standard_normal(4096)), _r(rng.standard_normal(4096))
+    o = torch.empty(4096, dtype=BF, device="cuda")
+    ops.add(b(a_), b(b_), o)
+    torch.cuda.synchronize()
+    assert maxdiff(o.float().cpu().numpy(), a_ + b_) <= np.abs(a_ + b_).max() * EPS
+
+
+def test_loss_gradient_rows_in_bf16_and_stem_weight_gradient():
+    """The loss kernel with bf16 gradient rows = its fp32 rows rounded once; the stem's weight gradient from a bf16 dz =
+    the fp32 kernel on the widened dz."""
+    from viddet_amd import ops
+    from tests.test_yolo_gpu import _heads, _gt, _desc
+    b, c, size, m = 2, 20, 128, 5
+    grids = [size // 32, size // 16, size // 8]
+    rng = np.random.default_rng(77)
+    heads = _heads(rng, b, c, grids, -1.0)
+    gt, ids = _gt(rng, b, m, size, c, [4, 2])
+    tg = Y.prefetch_targets(size, size, grids, gt, ids, c)
+    h, hd, _, ldh = _desc(ops, heads, c, b)
+    P = 3 * sum(g * g for g in grids)
+    ws = torch.empty(max(16, ops.yolo_loss_ws_bytes(h)), dtype=torch.uint8, device="cuda")
+    res = {}
+    for dt in (torch.float32, BF):
+        dh = [torch.full(t.shape, 5.0, dtype=dt, device="cuda") for t in hd]
+        losses = torch.empty(b, 4, device="cuda")
+        ops.yolo_loss_fwd_bwd(h, dev(gt), m, *[dev(t) for t in tg], 0.7, False, losses, dh, None, ws)
+        torch.cuda.synchronize()
+        res[dt] = (losses.clone(), dh)
+    assert torch.equal(res[torch.float32][0], res[BF][0])
+    for a_, b_ in zip(res[torch.float32][1], res[BF][1]):
+        assert torch.equal(a_.to(BF), b_)
+    # stem weight gradient
+    n, hh, ww = 2, 24, 20
+    x = torch.randn(n, 3, hh, ww, device="cuda")
+    dz = torch.randn(n, hh, ww, 32, device="cuda").to(BF)
+    wsz = torch.empty(int(ops._lib().vd_stem_wgrad_ws_bytes(n, hh, ww)), dtype=torch.uint8, device="cuda")
+    d1, d2 = torch.empty(32, 32, device="cuda"), torch.empty(32, 32, device="cuda")
+    ops.stem_wgrad(x, dz, d1, wsz)
+    ops.stem_wgrad(x, dz.float(), d2, wsz)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2)

@@ -15,9 +15,10 @@ constexpr int RED_THREADS = 256;
 
 // MODE 0: a = x, b = x*x          (forward statistics)
 // MODE 1: a = g, b = g*xhat       (backward reductions), g = dy * leaky'(x*scale+shift)
-template <int MODE>
-__global__ __launch_bounds__(RED_THREADS) void k_bn_partial(const float* __restrict__ x,
-                                                            const float* __restrict__ dy,
+// T: storage type of x / dy (float, or __bf16 for bf16-storage training: fp32 arithmetic on the widened values)
+template <int MODE, typename T = float>
+__global__ __launch_bounds__(RED_THREADS) void k_bn_partial(const T* __restrict__ x,
+                                                            const T* __restrict__ dy,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
@@ -44,12 +45,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_partial(const float* __restr
                 is = reinterpret_cast<const f32x4*>(invstd)[col];
             }
             for (int64_t r = r0 + trow; r < r1; r += rl) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(x)[r * cvec + col];
+                const f32x4 v = vd_ld4(x, r * cvec + col);
                 if (MODE == 0) {
                     a += v;
                     b += v * v;
                 } else {
-                    const f32x4 d = reinterpret_cast<const f32x4*>(dy)[r * cvec + col];
+                    const f32x4 d = vd_ld4(dy, r * cvec + col);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float u = v[e] * sc[e] + sh[e];
@@ -254,34 +255,36 @@ __global__ void k_bn_fold_eval(const float* __restrict__ gamma, const float* __r
 // Streaming kernels below: the launch makes gridDim.x * 256 a multiple of cvec (fixed_col_blocks), so a thread's float4
 // column col = i % cvec never changes along its grid-stride loop - the per-channel constants are loaded (and the fp64
 // sums converted) once per thread instead of once per element, and the 64-bit modulo leaves the loop.
-__global__ void k_bn_apply_leaky(const float* __restrict__ x, const float* __restrict__ scale,
-                                 const float* __restrict__ shift, const float* __restrict__ res,
-                                 float* __restrict__ y, int64_t n4, int cvec, float slope, float* __restrict__ amax) {
+template <typename T = float>
+__global__ void k_bn_apply_leaky(const T* __restrict__ x, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, const T* __restrict__ res,
+                                 T* __restrict__ y, int64_t n4, int cvec, float slope, float* __restrict__ amax) {
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int col = (int)(i0 % cvec);
     const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col];
     const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[col];
     float amx = 0.f;
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 v = vd_ld4(x, i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float u = v[e] * sc[e] + sh[e];
             o[e] = u > 0.f ? u : u * slope;
         }
-        if (res) o += reinterpret_cast<const f32x4*>(res)[i];
-        reinterpret_cast<f32x4*>(y)[i] = o;
+        if (res) o += vd_ld4(res, i);
+        vd_st4(y, i, o);
         amx = fmaxf(amx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     if (amax) vd_amax_publish(amax, amx);       // max-abs of the tensor for its consumers' fp16 operand scale
 }
 
-__global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T = float>
+__global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dy,
                                const float* __restrict__ scale, const float* __restrict__ shift,
                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                const double* __restrict__ sums2, double count, int64_t n4, int C,
-                               float slope, float* __restrict__ dx, float* __restrict__ amax) {
+                               float slope, T* __restrict__ dx, float* __restrict__ amax) {
     const int cvec = C >> 2;
     const float inv_count = (float)(1.0 / count);
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,8 +301,8 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restr
     }
     float amx = 0.f;
     for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 v = vd_ld4(x, i);
+        const f32x4 d = vd_ld4(dy, i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -308,7 +311,7 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restr
             const float xh = (v[e] - mu[e]) * is[e];
             o[e] = sc[e] * (g - mg[e] - xh * mgx[e]);
         }
-        reinterpret_cast<f32x4*>(dx)[i] = o;
+        vd_st4(dx, i, o);
         amx = fmaxf(amx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
     if (amax) vd_amax_publish(amax, amx);
@@ -360,8 +363,8 @@ int vd_bn_stats(const float* x, int64_t M, int C, double* sums, void* ws, int64_
         return VD_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_partial<0>, dim3(nb), dim3(RED_THREADS), 0, s, x, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, M, C, 0.f, (float*)ws);
+    hipLaunchKernelGGL((k_bn_partial<0, float>), dim3(nb), dim3(RED_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0.f, (float*)ws);
     VD_CHECK_LAUNCH("vd_bn_stats");
     hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb,
                        2 * C, sums);
@@ -452,7 +455,7 @@ int vd_bn_apply_leaky(const float* x, const float* scale, const float* shift, co
                       int64_t M, int C, float slope, float* amax_out, void* stream) {
     VD_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && C % 4 == 0, "vd_bn_apply_leaky: bad args");
     const int64_t n4 = M * (C / 4);
-    hipLaunchKernelGGL(k_bn_apply_leaky, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+    hipLaunchKernelGGL(k_bn_apply_leaky<float>, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        residual, y, n4, C / 4, slope, amax_out);
     VD_CHECK_LAUNCH("vd_bn_apply_leaky");
     return VD_OK;
@@ -469,7 +472,7 @@ int vd_bn_bwd_reduce(const float* x, const float* dy, const float* scale, const 
         return VD_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_partial<1>, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, scale, shift, save_mean, save_invstd,
+    hipLaunchKernelGGL((k_bn_partial<1, float>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, scale, shift, save_mean, save_invstd,
                        M, C, slope, (float*)ws);
     VD_CHECK_LAUNCH("vd_bn_bwd_reduce");
     hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb,
@@ -492,9 +495,69 @@ int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const f
     VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && dx && count > 0 && C % 4 == 0,
                "vd_bn_bwd_apply: bad args");
     const int64_t n4 = M * (C / 4);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, scale, shift,
                        save_mean, save_invstd, sums2, count, n4, C, slope, dx, amax_out);
     VD_CHECK_LAUNCH("vd_bn_bwd_apply");
+    return VD_OK;
+}
+
+// ---- bf16-storage training (BASELINE configs[4]): the same passes on bf16 tensors - fp32 arithmetic on the widened values,
+// fp32 per-channel vectors, fp64 [2C] sums; x / dy / y / dx are bf16 [M, C]
+int vd_bn_stats_bf16(const void* x, int64_t M, int C, double* sums, void* ws, int64_t ws_bytes, void* stream) {
+    VD_REQUIRE(x && sums && ws && M > 0 && C > 0 && C % 4 == 0, "vd_bn_stats_bf16: bad args (C=%d)", C);
+    const int nb = red_blocks(M);
+    if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
+        vd_set_error("vd_bn_stats_bf16: workspace too small");
+        return VD_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_bn_partial<0, __bf16>), dim3(nb), dim3(RED_THREADS), 0, s, (const __bf16*)x, (const __bf16*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0.f, (float*)ws);
+    VD_CHECK_LAUNCH("vd_bn_stats_bf16");
+    hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb, 2 * C, sums);
+    VD_CHECK_LAUNCH("vd_bn_stats_bf16/sum");
+    return VD_OK;
+}
+
+int vd_bn_apply_leaky_bf16(const void* x, const float* scale, const float* shift, const void* residual, void* y,
+                           int64_t M, int C, float slope, void* stream) {
+    VD_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && C % 4 == 0, "vd_bn_apply_leaky_bf16: bad args");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(k_bn_apply_leaky<__bf16>, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x,
+                       scale, shift, (const __bf16*)residual, (__bf16*)y, n4, C / 4, slope, (float*)nullptr);
+    VD_CHECK_LAUNCH("vd_bn_apply_leaky_bf16");
+    return VD_OK;
+}
+
+int vd_bn_bwd_reduce_bf16(const void* x, const void* dy, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_invstd, int64_t M, int C, float slope, double* sums2, void* ws, int64_t ws_bytes,
+                          void* stream) {
+    VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && ws && M > 0 && C % 4 == 0,
+               "vd_bn_bwd_reduce_bf16: bad args");
+    const int nb = red_blocks(M);
+    if (ws_bytes < (int64_t)nb * 2 * C * (int64_t)sizeof(float)) {
+        vd_set_error("vd_bn_bwd_reduce_bf16: workspace too small");
+        return VD_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_bn_partial<1, __bf16>), dim3(nb), dim3(RED_THREADS), 0, s, (const __bf16*)x, (const __bf16*)dy, scale, shift,
+                       save_mean, save_invstd, M, C, slope, (float*)ws);
+    VD_CHECK_LAUNCH("vd_bn_bwd_reduce_bf16");
+    hipLaunchKernelGGL(k_bn_sum_partials, dim3((unsigned)vd_cdiv(2 * C, 64)), dim3(1024), 0, s, (const float*)ws, nb, 2 * C, sums2);
+    VD_CHECK_LAUNCH("vd_bn_bwd_reduce_bf16/sum");
+    return VD_OK;
+}
+
+int vd_bn_bwd_apply_bf16(const void* x, const void* dy, const float* scale, const float* shift, const float* save_mean,
+                         const float* save_invstd, const double* sums2, double count, int64_t M, int C, float slope,
+                         void* dx, void* stream) {
+    VD_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && sums2 && dx && count > 0 && C % 4 == 0,
+               "vd_bn_bwd_apply_bf16: bad args");
+    const int64_t n4 = M * (C / 4);
+    hipLaunchKernelGGL(k_bn_bwd_apply<__bf16>, dim3(fixed_col_blocks(n4, C / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x,
+                       (const __bf16*)dy, scale, shift, save_mean, save_invstd, sums2, count, n4, C, slope, (__bf16*)dx,
+                       (float*)nullptr);
+    VD_CHECK_LAUNCH("vd_bn_bwd_apply_bf16");
     return VD_OK;
 }
 

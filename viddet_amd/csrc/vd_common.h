@@ -11,6 +11,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void vd_set_error(const char* fmt, ...);
 
+// std::conditional without <type_traits> in device code
+template <bool B, typename T, typename F> struct vd_select { typedef T type; };
+template <typename T, typename F> struct vd_select<false, T, F> { typedef F type; };
+
+// ---- storage-type generic 4- / 8-element accesses of the streaming kernels (fp32 or bf16 tensors, fp32 arithmetic) ----
+typedef __bf16 vd_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 vd_ld4(const float* p, int64_t i4) { return reinterpret_cast<const f32x4*>(p)[i4]; }
+__device__ __forceinline__ f32x4 vd_ld4(const __bf16* p, int64_t i4) {
+    const vd_bf16x4 v = reinterpret_cast<const vd_bf16x4*>(p)[i4];
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void vd_st4(float* p, int64_t i4, const f32x4 v) { reinterpret_cast<f32x4*>(p)[i4] = v; }
+__device__ __forceinline__ void vd_st4(__bf16* p, int64_t i4, const f32x4 v) {
+    vd_bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];           // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    reinterpret_cast<vd_bf16x4*>(p)[i4] = o;
+}
+__device__ __forceinline__ f32x8 vd_ld8(const __bf16* p, int64_t i8) {
+    const vd_bf16x8 v = reinterpret_cast<const vd_bf16x8*>(p)[i8];
+    f32x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    return o;
+}
+__device__ __forceinline__ void vd_st8(__bf16* p, int64_t i8, const f32x8 v) {
+    vd_bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    reinterpret_cast<vd_bf16x8*>(p)[i8] = o;
+}
+
 #define VD_REQUIRE(cond, ...)                                   \
     do {                                                        \
         if (!(cond)) {                                          \

@@ -1373,10 +1373,14 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c
 
 // second launch bound = waves per SIMD the kernel must fit: two workgroups per CU for the fp32-MFMA tiles (the
 // 8-wave ones must stay within 128 VGPRs), one 8-wave workgroup for the split-math tiles
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, int NPL = 3>
+// BF (VD_STORE_BF16, bf16-storage training): `in` and `dout` are bf16 tensors - a lane's four channels are one 8-byte
+// load that goes to the (single) LDS plane untouched; the weight gradient itself stays fp32.
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, int NPL = 3, bool BF = false>
 __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
+    static_assert(!BF || (SP && NPL == 1 && !XF), "bf16-stored operands: one plane, no in-load transform");
+    using LT = typename vd_select<BF, uint2, f32x4>::type;      // what a lane holds of one (pixel, 4 channels)
     constexpr int BM = WM * TM * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
     static_assert(WN * TN * 32 == WG_BN && (WM * WN == 4 || WM * WN == 8), "tile");
@@ -1468,9 +1472,9 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
 
     // register sets (k_conv_igemm has the rationale); the 64x64-per-wave tiles have no VGPRs left for a third
     constexpr int PD = (SP && TM * TN == 2) ? 3 : 2;
-    f32x4 ra[PD][APASS], rb[PD][BPASS];
+    LT ra[PD][APASS], rb[PD][BPASS];
     int64_t next_p = p_begin;                 // first pixel of the next tile to request
-    auto gload = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+    auto gload = [&](LT (&ra)[APASS], LT (&rb)[BPASS]) {
         const int64_t pbase = next_p;
         next_p += WG_BP;
 #pragma unroll
@@ -1478,7 +1482,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const int64_t pix = pbase + alpix + AROWS * i;
             const bool ok = pix < p_end && co_ok;
             const int64_t sel = ok ? pix * p.ldd + co : zd_do;
-            ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
+            if constexpr (BF) ra[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
+            else ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
         }
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
@@ -1490,16 +1495,20 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                              (unsigned)fz < (unsigned)p.Kfr;
             const int64_t o = (int64_t)((n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride) * p.Ci + boff;
             const int64_t sel = bok ? o : zd_in;
-            f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + sel);
-            if (XF) {
+            if constexpr (BF) {
+                rb[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.in) + sel);
+            } else {
+                f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + sel);
+                if (XF) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float tt = vb[e] * sc[e] + sh[e];
-                    tt = tt > 0.f ? tt : tt * p.in_slope;
-                    vb[e] = bok ? tt : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        float tt = vb[e] * sc[e] + sh[e];
+                        tt = tt > 0.f ? tt : tt * p.in_slope;
+                        vb[e] = bok ? tt : 0.f;
+                    }
                 }
+                rb[i] = vb;
             }
-            rb[i] = vb;
             // advance the cursor by WG_BP pixels
             int nx = gx + step_x, ny = gy + step_y;
             if (nx >= p.Wg) { nx -= p.Wg; ++ny; }
@@ -1513,8 +1522,22 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             cgx[i] = nx; cgy[i] = ny; cn[i] = nn;
         }
     };
-    auto lstore = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
-        if (SP) {
+    auto lstore = [&](int buf, const LT (&ra)[APASS], const LT (&rb)[BPASS]) {
+        if constexpr (BF) {
+            char* a3 = As3 + buf * NPL * APL + (alc & 31) * 2;
+            char* b3 = Bs3 + buf * NPL * BPL + (blc & 31) * 2;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int px = alpix + AROWS * i;
+                *reinterpret_cast<uint2*>(a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6)) = ra[i];
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int px = blpix + BROWS * i;
+                *reinterpret_cast<uint2*>(b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6)) = rb[i];
+            }
+            return;
+        } else if constexpr (SP) {
             char* a3 = As3 + buf * NPL * APL + (alc & 31) * 2;
             char* b3 = Bs3 + buf * NPL * BPL + (blc & 31) * 2;
 #pragma unroll
@@ -1552,13 +1575,14 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                 *reinterpret_cast<uint2*>(r) = h;
             }
             return;
+        } else {
+            float* a = As + buf * WG_BP * BM;
+            float* bb = Bs + buf * WG_BP * WG_BN;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + (alpix + AROWS * i) * BM + alc) = ra[i];
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + BROWS * i) * WG_BN + blc) = rb[i];
         }
-        float* a = As + buf * WG_BP * BM;
-        float* bb = Bs + buf * WG_BP * WG_BN;
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + (alpix + AROWS * i) * BM + alc) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(bb + (blpix + BROWS * i) * WG_BN + blc) = rb[i];
     };
     auto compute = [&](int buf) {
         if (SP) {
@@ -1683,9 +1707,11 @@ __global__ void k_reduce_slabs(const float* __restrict__ ws, float* __restrict__
     reinterpret_cast<f32x4*>(dst)[i] = a;
 }
 
-bool wgrad_split_math(const vd_wgrad_desc& d) { return (d.flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) && d.Co >= 64; }
+bool wgrad_split_math(const vd_wgrad_desc& d) {
+    return (d.flags & VD_STORE_BF16) || ((d.flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) && d.Co >= 64);
+}
 int wgrad_bm(const vd_wgrad_desc& d) {
-    if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : (d.Co >= 128 ? 128 : 64);
+    if (wgrad_split_math(d)) return d.Co >= 256 ? 256 : (d.Co >= 128 ? 128 : 64);      // (bf16 storage, Co = 32: half a 64-row tile)
     return d.Co <= 32 ? 32 : (d.Co <= 64 ? 64 : 128);
 }
 // workgroups resident at once: 2 per CU for the fp32-MFMA tiles, 1 per CU for the split-math tiles (LDS)
@@ -1719,6 +1745,23 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
     if (s < 1) s = 1;
     if (s > 512) s = 512;
     return (int)s;
+}
+
+template <int WM, int WN, int TM, int TN>
+void launch_wgrad_bf(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int lds = 2 * WG_BP * (BM + WG_BN) * 2;
+    auto kfn = k_conv_wgrad<WM, WN, TM, TN, false, true, 1, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int64_t tiles = vd_cdiv(d.Co, BM) * vd_cdiv((int64_t)d.T * d.Ci, WG_BN);
+    // the zero page, as bf16 element offsets from the two (bf16) tensors
+    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page());
+    const int64_t zd_in = zp - reinterpret_cast<const __bf16*>(d.in), zd_do = zp - reinterpret_cast<const __bf16*>(d.dout);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tiles * splits)), dim3(WM * WN * 64), lds, s, d, dst, splits, pps, zd_in, zd_do);
 }
 
 template <int WM, int WN, int TM, int TN, bool SP, int NPL>
@@ -1896,6 +1939,7 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_wgrad: bad Kfr");
     VD_REQUIRE(d->ldd >= d->Co && d->ldd % 4 == 0, "vd_conv_wgrad: bad ldd");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_wgrad: in_scale/in_shift mismatch");
+    VD_REQUIRE(!(d->flags & VD_STORE_BF16) || !d->in_scale, "vd_conv_wgrad: no in-load transform on bf16-stored operands");
     VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || d->Co < 64 || (d->amax_in && d->amax_dout && !d->in_scale),
                "vd_conv_wgrad: VD_MATH_F16X2 needs amax_in and amax_dout (and no in-load transform)");
     VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31) && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31),
@@ -1911,7 +1955,11 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     int64_t pps = vd_cdiv(vd_cdiv(P, splits), WG_BP) * WG_BP;
     float* dst = (splits > 1) ? (float*)ws : d->dwp;
     const int bm = wgrad_bm(*d);
-    if (wgrad_split_math(*d)) {
+    if (d->flags & VD_STORE_BF16) {
+        if (bm == 256) launch_wgrad_bf<4, 2, 2, 2>(*d, dst, splits, pps, s);
+        else if (bm == 128) launch_wgrad_bf<2, 4, 2, 1>(*d, dst, splits, pps, s);
+        else launch_wgrad_bf<2, 4, 1, 1>(*d, dst, splits, pps, s);
+    } else if (wgrad_split_math(*d)) {
         if (bm == 256) launch_wgrad<4, 2, 2, 2, true>(*d, dst, splits, pps, s);        // 256x128, 8 waves of 64x64
         else if (bm == 128) launch_wgrad<2, 4, 2, 1, true>(*d, dst, splits, pps, s);   // 128x128, 8 waves of 64x32
         else launch_wgrad<2, 4, 1, 1, true>(*d, dst, splits, pps, s);                  //  64x128, 8 waves of 32x32

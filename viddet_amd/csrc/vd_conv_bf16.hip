@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     }   // !HALO
 
     STAMP(4);
-    // ---- epilogue (fp32 math; direct geometry only: this path serves forward convs).  Per wave, one 32x32
+    // ---- epilogue (fp32 math).  Per wave, one 32x32
     // accumulator tile at a time is transposed through a private LDS patch so that each lane owns 4 consecutive
     // columns of 4 rows: scale/shift/LeakyReLU/residual on 4-vectors and 8-byte (bf16 x4) or 16-byte (fp32 heads)
     // stores instead of 2 bytes per lane.
@@ -415,6 +415,18 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     float* stg = reinterpret_cast<float*>(smem_b) + wave * (32 * SLD);
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
     const bool has_aff = p.flags & VD_EPI_AFFINE, has_res = p.flags & VD_EPI_RESIDUAL, has_leaky = p.flags & VD_EPI_LEAKY;
+    // output pixel of GEMM row m: the row itself (forward, stride-1 data gradients) or the strided / offset pixel of a
+    // stride-2 data gradient's parity class (vd_conv.hip has the same map)
+    const bool direct = (p.out_stride == 1 && p.out_oy == 0 && p.out_ox == 0 && p.Ho == p.Hg && p.Wo == p.Wg);
+    auto out_pix = [&](int64_t m) -> int64_t {
+        if (direct) return m;
+        const unsigned mu = (unsigned)m;
+        const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
+        const int gx = (int)(mu - t * (unsigned)p.Wg);
+        const unsigned n = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
+        const int gy = (int)(t - n * (unsigned)p.Hg);
+        return ((int64_t)n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
+    };
     const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) && (p.Co % 4 == 0) &&
                         (!has_res || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0))) &&
                         (!has_aff || (((uintptr_t)p.scale | (uintptr_t)p.shift) % 16 == 0));
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
                     for (int i = 0; i < 4; ++i) {
                         int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
                         m = m < M ? m : M - 1;
-                        rv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(res + m * p.ldr + (colv[ni] < 0 ? 0 : colv[ni]));
+                        rv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(res + out_pix(m) * p.ldr + (colv[ni] < 0 ? 0 : colv[ni]));
                     }
         }
 #pragma unroll
@@ -473,12 +485,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
                         for (int e = 0; e < 4; ++e) t[e] += (float)rv[mi][ni][i][e];
                     }
                     if (m < M && colv[ni] >= 0) {
-                        if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + m * p.ldo + colv[ni]) = t;
+                        const int64_t op = out_pix(m);
+                        if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + op * p.ldo + colv[ni]) = t;
                         else {
                             bf16x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = (__bf16)t[e];
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + m * p.ldo + colv[ni]) = o;
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + op * p.ldo + colv[ni]) = o;
                         }
                     }
                 }
@@ -513,21 +526,64 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SLD + ec4);
                     const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
                     if (nvalid <= 0 || m >= M) continue;
+                    const int64_t op = out_pix(m);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (e < nvalid) {
                             float t = v[e];
                             if (has_aff) t = t * sc[e] + sh[e];
                             if (has_leaky) t = t > 0.f ? t : t * p.slope;
-                            if (has_res) t += (float)res[m * p.ldr + col + e];
-                            if (OUT_F32) p.out[m * p.ldo + col + e] = t;
-                            else reinterpret_cast<__bf16*>(p.out)[m * p.ldo + col + e] = (__bf16)t;
+                            if (has_res) t += (float)res[op * p.ldr + col + e];
+                            if (OUT_F32) p.out[op * p.ldo + col + e] = t;
+                            else reinterpret_cast<__bf16*>(p.out)[op * p.ldo + col + e] = (__bf16)t;
                         }
                 }
             }
         }
     }
     STAMP(5);
+    // ---- fused BatchNorm statistics (bf16-storage training forward): per-column sum / sum of squares of this block's raw
+    // conv outputs, from the fp32 ACCUMULATORS (before they are rounded to bf16), one row of the partial table
+    // [tile_m][2 * Co] per M tile - no atomics, vd_bn_sum_partials finishes in fp64 in a fixed order (as k_conv_igemm)
+    if (p.stats_part) {
+        __syncthreads();        // every wave is done with its staging patch
+        float* red = reinterpret_cast<float*>(smem_b);      // [WM][BN][2]
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = (m < M) ? acc[mi][ni][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 32) {
+                const int c = wn * TN * 32 + ni * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            const int col = tile_n * BN + c;
+            if (col < p.Co) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    s1 += red[(w * BN + c) * 2 + 0];
+                    s2 += red[(w * BN + c) * 2 + 1];
+                }
+                float* dstp = p.stats_part + (int64_t)tile_m * 2 * p.Co;
+                dstp[col] = s1;
+                dstp[p.Co + col] = s2;
+            }
+        }
+    }
 #if VD_STAMP
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[6] = wall_clock64();
 #endif
@@ -654,16 +710,33 @@ __global__ void k_stem_im2col_bf16(const float* __restrict__ in, __bf16* __restr
 
 extern "C" {
 
+// rows of the GEMM one workgroup covers, per tile variant (dispatch_b below)
+static int bf16_tile_bm(const vd_conv_desc& d) {
+    int tile = d.tile;
+    if (d.Ci == 32) return tile == 13 ? 128 : 256;
+    if (tile <= 0 || tile > 13) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
+    switch (tile) {
+        case 10: case 11: case 12: case 8: case 9: case 6: return 256;
+        case 13: case 7: case 1: case 2: case 3: return 128;
+        default: return 64;
+    }
+}
+
+int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d) {
+    if (!d) return 0;
+    return (int)vd_cdiv((int64_t)d->N * d->Hg * d->Wg, bf16_tile_bm(*d));
+}
+
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
     VD_REQUIRE(d && d->in && d->wp && d->out, "vd_conv_igemm_bf16: null pointer");
     VD_REQUIRE(d->Ci == 32 || (d->Ci > 0 && d->Ci % 64 == 0), "vd_conv_igemm_bf16: Ci=%d must be 32 or a positive multiple of 64", d->Ci);
     VD_REQUIRE(d->T >= 1 && d->T <= VD_MAX_TAPS && d->Kfr >= 1 && d->N % d->Kfr == 0, "vd_conv_igemm_bf16: bad taps");
-    VD_REQUIRE(d->out_stride == 1 && d->out_oy == 0 && d->out_ox == 0 && d->Ho == d->Hg && d->Wo == d->Wg,
-               "vd_conv_igemm_bf16: forward geometry only");
+    VD_REQUIRE(d->out_stride >= 1 && d->out_oy >= 0 && d->out_ox >= 0 && (d->Hg - 1) * d->out_stride + d->out_oy < d->Ho &&
+               (d->Wg - 1) * d->out_stride + d->out_ox < d->Wo, "vd_conv_igemm_bf16: output geometry");
     VD_REQUIRE(d->ldo >= d->Co && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31) && (int64_t)d->N * d->Hg * d->Wg < (1ll << 31),
                "vd_conv_igemm_bf16: bad sizes");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
-    VD_REQUIRE(!d->in_scale && !d->stats_part, "vd_conv_igemm_bf16: in-load transform / fused statistics are fp32-path features");
+    VD_REQUIRE(!d->in_scale && !d->bs_part, "vd_conv_igemm_bf16: in-load transform / fused backward reductions are fp32-path features");
     static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
     vd_conv_desc dd = *d;
     dd.flags |= (probe & 7) << 8;

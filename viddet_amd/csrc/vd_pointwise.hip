@@ -36,6 +36,11 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
     if (t < n) o[t] = a[t] + b[t];
 }
 
+// bf16 tensors, fp32 sums (bf16-storage training): n8 groups of 8 elements
+__global__ void k_add_bf16(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ o, int64_t n8) {
+    GRID_STRIDE(i, n8) { vd_st8(o, i, vd_ld8(a, i) + vd_ld8(b, i)); }
+}
+
 // max-abs of x[0..n) into the tensor's amax sub-slots (vd_common.h); float4 body + scalar tail
 __device__ __forceinline__ float amax_range(const float* __restrict__ x, int64_t n, int64_t first, int64_t stride) {
     float m = 0.f;
@@ -109,6 +114,27 @@ __global__ void k_upcat_bwd_up(const float* __restrict__ dout, float* __restrict
         s += d[(base + Wo) * Ct4 + c];
         s += d[(base + Wo + 1) * Ct4 + c];
         reinterpret_cast<f32x4*>(dup)[i] = s;
+    }
+}
+
+// the same on bf16 tensors (the four gradients are summed in fp32 and rounded once); C*8 = channel groups of 8
+__global__ void k_upcat_bwd_up_bf16(const __bf16* __restrict__ dout, __bf16* __restrict__ dup, int N, int Ho, int Wo,
+                                    int Cu8, int Ct8) {
+    const int Hu = Ho >> 1, Wu = Wo >> 1;
+    const int64_t total = (int64_t)N * Hu * Wu * Cu8;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cu8);
+        const int64_t pix = i / Cu8;
+        const int x = (int)(pix % Wu);
+        const int64_t t = pix / Wu;
+        const int y = (int)(t % Hu);
+        const int64_t n = t / Hu;
+        const int64_t base = ((n * Ho + 2 * y) * Wo + 2 * x);
+        f32x8 s = vd_ld8(dout, base * Ct8 + c);
+        s += vd_ld8(dout, (base + 1) * Ct8 + c);
+        s += vd_ld8(dout, (base + Wo) * Ct8 + c);
+        s += vd_ld8(dout, (base + Wo + 1) * Ct8 + c);
+        vd_st8(dup, i, s);
     }
 }
 
@@ -262,6 +288,14 @@ int vd_add(const float* a, const float* b, float* out, int64_t n, void* stream) 
     return VD_OK;
 }
 
+int vd_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    VD_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "vd_add_bf16: bad args (n must be a multiple of 8)");
+    hipLaunchKernelGGL(k_add_bf16, dim3(sblocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b,
+                       (__bf16*)out, n / 8);
+    VD_CHECK_LAUNCH("vd_add_bf16");
+    return VD_OK;
+}
+
 int vd_fill(float* out, float v, int64_t n, void* stream) {
     VD_REQUIRE(out && n > 0, "vd_fill: bad args");
     hipLaunchKernelGGL(k_fill, dim3(sblocks(n)), dim3(256), 0, (hipStream_t)stream, out, v, n);
@@ -329,6 +363,27 @@ int vd_upsample2x_concat_bwd(const float* dout, float* dup, float* droute, int N
         hipLaunchKernelGGL(k_upcat_bwd_route, dim3(sblocks(npix * (Cr / 4))), dim3(256), 0, s, dout, droute, npix, Cu / 4,
                            Cr / 4);
         VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd/route");
+    }
+    return VD_OK;
+}
+
+/* bf16 tensors.  The forward concat and the route half of the backward are copies: run them through vd_upsample2x_concat /
+ * this entry's route launch with the channel counts halved (two bf16 = one 4-byte word); the up half sums four gradients. */
+int vd_upsample2x_concat_bwd_bf16(const void* dout, void* dup, void* droute, int N, int Ho, int Wo, int Cu, int Cr, void* stream) {
+    VD_REQUIRE(dout && (dup || droute) && N > 0 && Ho % 2 == 0 && Wo % 2 == 0 && Cu % 8 == 0 && Cr % 8 == 0,
+               "vd_upsample2x_concat_bwd_bf16: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (dup) {
+        const int64_t t1 = (int64_t)N * (Ho / 2) * (Wo / 2) * (Cu / 8);
+        hipLaunchKernelGGL(k_upcat_bwd_up_bf16, dim3(sblocks(t1)), dim3(256), 0, s, (const __bf16*)dout, (__bf16*)dup, N, Ho, Wo, Cu / 8,
+                           (Cu + Cr) / 8);
+        VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd_bf16/up");
+    }
+    if (droute) {
+        const int64_t npix = (int64_t)N * Ho * Wo;
+        hipLaunchKernelGGL(k_upcat_bwd_route, dim3(sblocks(npix * (Cr / 8))), dim3(256), 0, s, (const float*)dout, (float*)droute, npix,
+                           Cu / 8, Cr / 8);
+        VD_CHECK_LAUNCH("vd_upsample2x_concat_bwd_bf16/route");
     }
     return VD_OK;
 }

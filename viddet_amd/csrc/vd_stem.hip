@@ -129,7 +129,8 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
 // Weight gradient.  One wave owns a run of pixels; per MFMA (K = 2 pixels): A[co = lane&31][px = lane>>5] = dz, coalesced
 // 128-B rows; B[px][k = lane&31] = x[n][c(k)][y + dy(k)][x + dx(k)] (zero outside the frame and for k >= 27).
 // part: [gridDim.x * 4 waves][32 co][32 k] partial tiles, summed in wave order by k_stem_wgrad_reduce.
-__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dz, int ldd,
+template <typename T>      // storage type of dz (float, or __bf16 in bf16-storage training)
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const T* __restrict__ dz, int ldd,
                                                     float* __restrict__ part, int N, int H, int W, int64_t px_per_wave) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t HW = (int64_t)H * W, P = (int64_t)N * HW;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
         for (int u = 0; u < UNR; ++u) {
             const int64_t pu = p + 2 * u;
             const bool in_run = pu < p_end;
-            a[u] = in_run ? dz[pu * ldd + k] : 0.f;                          // k doubles as co for the A operand
+            a[u] = in_run ? (float)dz[pu * ldd + k] : 0.f;                   // k doubles as co for the A operand
             const int iy = y + dy, ix = xx + dx;
             const bool ok = in_run && k_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             b[u] = ok ? x[((int64_t)n * 3 + c) * HW + (int64_t)iy * W + ix] : 0.f;
@@ -214,7 +215,7 @@ int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N
                  const float* shift, float slope, int flags, int out_bf16, float* stats_part, void* stream) {
     VD_REQUIRE(x_nchw && wp && out && N > 0 && H > 0 && W > 0 && ldo >= SC && ldo % 4 == 0, "vd_stem_conv: bad args");
     VD_REQUIRE(!(flags & VD_EPI_AFFINE) || (scale && shift), "vd_stem_conv: affine epilogue needs scale and shift");
-    VD_REQUIRE(!stats_part || (flags == 0 && !out_bf16), "vd_stem_conv: fused statistics need the raw fp32 output");
+    VD_REQUIRE(!stats_part || flags == 0, "vd_stem_conv: fused statistics need the raw output (they come from the fp32 values, bf16 output or not)");
     VD_REQUIRE((int64_t)N * H * W < (1ll << 31), "vd_stem_conv: pixel count overflows int32");
     const int nb = vd_stem_conv_blocks(N, H, W);
     if (out_bf16)
@@ -235,8 +236,8 @@ int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W) {
     return (waves + STEM_RED_CHUNKS) * SC * 32 * (int64_t)sizeof(float);
 }
 
-int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
-                  void* stream) {
+static int stem_wgrad_any(const float* x_nchw, const void* dz, int dz_bf16, int ldd, float* dwp, int N, int H, int W, void* ws,
+                         int64_t ws_bytes, void* stream) {
     VD_REQUIRE(x_nchw && dz && dwp && N > 0 && H > 0 && W > 0 && ldd >= SC, "vd_stem_wgrad: bad args");
     const int64_t need = vd_stem_wgrad_ws_bytes(N, H, W);
     if (!ws || ws_bytes < need) {
@@ -248,7 +249,12 @@ int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int
     int64_t ppw = vd_cdiv(P, waves);
     ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, dz, ldd, (float*)ws, N, H, W, ppw);
+    if (dz_bf16)
+        hipLaunchKernelGGL(k_stem_wgrad<__bf16>, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, (const __bf16*)dz, ldd, (float*)ws,
+                           N, H, W, ppw);
+    else
+        hipLaunchKernelGGL(k_stem_wgrad<float>, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, (const float*)dz, ldd, (float*)ws,
+                           N, H, W, ppw);
     VD_CHECK_LAUNCH("vd_stem_wgrad");
     float* lvl1 = (float*)ws + waves * (SC * 32);
     hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, STEM_RED_CHUNKS), dim3(256), 0, s, (const float*)ws, (int)waves, lvl1);
@@ -256,6 +262,17 @@ int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int
     hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, 1), dim3(256), 0, s, (const float*)lvl1, STEM_RED_CHUNKS, dwp);
     VD_CHECK_LAUNCH("vd_stem_wgrad/reduce2");
     return VD_OK;
+}
+
+int vd_stem_wgrad(const float* x_nchw, const float* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
+                  void* stream) {
+    return stem_wgrad_any(x_nchw, dz, 0, ldd, dwp, N, H, W, ws, ws_bytes, stream);
+}
+
+/* dz stored as bf16 (bf16-storage training); frames and the weight gradient stay fp32 */
+int vd_stem_wgrad_bf16(const float* x_nchw, const void* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
+                       void* stream) {
+    return stem_wgrad_any(x_nchw, dz, 1, ldd, dwp, N, H, W, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -327,14 +327,15 @@ constexpr int LOSS_MAX_GT = 256;
 // gradient.  (Round 2's form read and wrote 4 B per lane at unaligned anchor offsets and ran decode + the gt loop on
 // lanes 0..2 of every wave: 1.18 TB/s.)  VEC = 16-B accesses (ldh % 4 == 0, 16-B aligned tensors: every plan of the
 // network); the scalar form stays for odd pitches.
-template <bool VEC>
+// GT = storage type of the gradient rows dh* (float, or __bf16 in bf16-storage training: the head logits stay fp32)
+template <bool VEC, typename GT = float>
 __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const float* __restrict__ gt, int M,
                                                    const float* __restrict__ obj_t,
                                                    const float* __restrict__ center_t,
                                                    const float* __restrict__ scale_t,
                                                    const float* __restrict__ weight_t,
                                                    const float* __restrict__ class_t, float ignore_thresh,
-                                                   int label_smooth, float* dh0, float* dh1, float* dh2,
+                                                   int label_smooth, GT* dh0, GT* dh1, GT* dh2,
                                                    float* __restrict__ box_out, float* __restrict__ part,
                                                    float* am0, float* am1, float* am2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
         const int g = h.g[s];
         const int64_t hoff = ((int64_t)b * g * g + pix) * h.ldh;
         const float* src = h.head[s] + hoff;
-        float* dst = (s == 0 ? dh0 : (s == 1 ? dh1 : dh2)) + hoff;
+        GT* dst = (s == 0 ? dh0 : (s == 1 ? dh1 : dh2)) + hoff;
         if (VEC) {
             for (int e = 4 * lane; e < RW; e += 256) *reinterpret_cast<f32x4*>(row + e) = *reinterpret_cast<const f32x4*>(src + e);
         } else {
@@ -452,12 +453,12 @@ __global__ __launch_bounds__(256) void k_yolo_loss(const vd_head_desc h, const f
                     gv[q] = grad_of(e + q);
                     amx_r = fmaxf(amx_r, fabsf(gv[q]));
                 }
-                *reinterpret_cast<f32x4*>(dst + e) = gv;
+                vd_st4(dst, e >> 2, gv);
             }
         } else {
             for (int e = lane; e < h.ldh; e += 64) {
                 const float gv = grad_of(e);
-                dst[e] = gv;
+                dst[e] = (GT)gv;
                 amx_r = fmaxf(amx_r, fabsf(gv));
             }
         }
@@ -562,9 +563,9 @@ int64_t vd_yolo_loss_ws_bytes(const vd_head_desc* h) {
     return (int64_t)h->B * loss_blocks(h) * 4 * (int64_t)sizeof(float);
 }
 
-int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
+static int yolo_loss_any(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
                          const float* scale_t, const float* weight_t, const float* class_t, float ignore_thresh,
-                         int label_smooth, float* losses, float* const dhead[3], float* box_out,
+                         int label_smooth, float* losses, void* const dhead[3], int dhead_bf16, float* box_out,
                          float* const dhead_amax[3], void* ws, int64_t ws_bytes, void* stream) {
     VD_REQUIRE(head_ok(h), "vd_yolo_loss_fwd_bwd: bad head descriptor");
     VD_REQUIRE(obj_t && center_t && scale_t && weight_t && class_t && losses && dhead && dhead[0] && dhead[1] && dhead[2],
@@ -585,16 +586,38 @@ int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const fl
     uintptr_t al = 0;
     for (int i = 0; i < 3; ++i) al |= (uintptr_t)h->head[i] | (uintptr_t)dhead[i];
     const bool vec = (h->ldh % 4 == 0) && (al % 16 == 0);
-    auto kfn = vec ? k_yolo_loss<true> : k_yolo_loss<false>;
-    hipLaunchKernelGGL(kfn, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t,
-                       class_t, ignore_thresh, label_smooth, dhead[0], dhead[1], dhead[2], box_out, (float*)ws,
-                       dhead_amax ? dhead_amax[0] : nullptr, dhead_amax ? dhead_amax[1] : nullptr,
-                       dhead_amax ? dhead_amax[2] : nullptr);
+    float* a0 = dhead_amax ? dhead_amax[0] : nullptr, *a1 = dhead_amax ? dhead_amax[1] : nullptr, *a2 = dhead_amax ? dhead_amax[2] : nullptr;
+    if (dhead_bf16) {
+        auto kfn = vec ? k_yolo_loss<true, __bf16> : k_yolo_loss<false, __bf16>;
+        hipLaunchKernelGGL(kfn, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh,
+                           label_smooth, (__bf16*)dhead[0], (__bf16*)dhead[1], (__bf16*)dhead[2], box_out, (float*)ws, a0, a1, a2);
+    } else {
+        auto kfn = vec ? k_yolo_loss<true, float> : k_yolo_loss<false, float>;
+        hipLaunchKernelGGL(kfn, dim3(nb, h->B), dim3(256), lds, s, *h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh,
+                           label_smooth, (float*)dhead[0], (float*)dhead[1], (float*)dhead[2], box_out, (float*)ws, a0, a1, a2);
+    }
     VD_CHECK_LAUNCH("vd_yolo_loss_fwd_bwd");
     hipLaunchKernelGGL(k_loss_finalize, dim3((unsigned)vd_cdiv(h->B * 4, 64)), dim3(64), 0, s, (const float*)ws, nb, losses,
                        h->B);
     VD_CHECK_LAUNCH("vd_yolo_loss_fwd_bwd/finalize");
     return VD_OK;
+}
+
+int vd_yolo_loss_fwd_bwd(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
+                         const float* scale_t, const float* weight_t, const float* class_t, float ignore_thresh,
+                         int label_smooth, float* losses, float* const dhead[3], float* box_out,
+                         float* const dhead_amax[3], void* ws, int64_t ws_bytes, void* stream) {
+    return yolo_loss_any(h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh, label_smooth, losses,
+                         (void* const*)dhead, 0, box_out, dhead_amax, ws, ws_bytes, stream);
+}
+
+/* bf16-storage training: the head logits (vd_head_desc.head) stay fp32, the gradient rows dhead[s] are bf16 [.., ldh] */
+int vd_yolo_loss_fwd_bwd_bf16(const vd_head_desc* h, const float* gt, int M, const float* obj_t, const float* center_t,
+                              const float* scale_t, const float* weight_t, const float* class_t, float ignore_thresh,
+                              int label_smooth, float* losses, void* const dhead[3], float* box_out, void* ws, int64_t ws_bytes,
+                              void* stream) {
+    return yolo_loss_any(h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh, label_smooth, losses, dhead, 1,
+                         box_out, nullptr, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -10,13 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VD_LIB: developer override for A/B-testing a differently built kernel library (tools/ only)
 LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hip.so")
 
-ABI_VERSION = 3          # include/viddet_hip.h VD_ABI_VERSION
+ABI_VERSION = 4          # include/viddet_hip.h VD_ABI_VERSION
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
 MATH_BF16 = 32         # products on bf16-rounded operands (one MFMA term), fp32 tensors and accumulation
 MATH_F16X2 = 64        # two-way fp16 operand split with per-tensor power-of-two scales (three MFMA terms, fp32-accurate)
 MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-staged one (A/B timing)
+STORE_BF16 = 256       # vd_wgrad_desc.flags: `in` / `dout` are bf16 tensors (bf16-storage training)
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
     "vd_conv_igemm_mtiles": (_i, [C.POINTER(ConvDesc)]),
     "vd_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _i, _p]),
+    "vd_conv_igemm_bf16_mtiles": (_i, [C.POINTER(ConvDesc)]),
     "vd_pack_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vd_stem_im2col_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
@@ -117,6 +119,16 @@ SIGNATURES = {
     "vd_yolo_loss_fwd_bwd": (_i, [C.POINTER(HeadDesc), _p, _i, _p, _p, _p, _p, _p, _f, _i, _p,
                                   C.POINTER(_fp * 3), _p, C.POINTER(_fp * 3), _p, _i64, _p]),
     "vd_sgd_momentum": (_i, [_p, _p, _p, _i64, _f, _f, _f, _f, _p]),
+    # bf16-storage training (include/viddet_hip.h, last section)
+    "vd_bn_stats_bf16": (_i, [_p, _i64, _i, _p, _p, _i64, _p]),
+    "vd_bn_apply_leaky_bf16": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "vd_bn_bwd_reduce_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),
+    "vd_bn_bwd_apply_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p]),
+    "vd_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "vd_upsample2x_concat_bwd_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vd_stem_wgrad_bf16": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p]),
+    "vd_yolo_loss_fwd_bwd_bf16": (_i, [C.POINTER(HeadDesc), _p, _i, _p, _p, _p, _p, _p, _f, _i, _p,
+                                       C.POINTER(_fp * 3), _p, _p, _i64, _p]),
 }
 
 _lib = None

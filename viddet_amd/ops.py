@@ -128,6 +128,36 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     return Ho, Wo
 
 
+def conv_igemm_bf16(x, wb, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo, out_stride=1, out_oy=0, out_ox=0,
+                    scale=None, shift=None, residual=None, ldr=0, leaky=False, slope=0.1, tile=0, stats_part=None, nohalo=False):
+    """vd_conv_igemm_bf16: x / wb / residual bf16, out bf16 or fp32 (by its dtype); any output geometry; stats_part =
+    fused BatchNorm statistics table [mtiles][2 * Co] (conv_bf16_mtiles)."""
+    d = ConvDesc()
+    d.tile = tile
+    d.in_, d.wp, d.out = ptr(x), ptr(wb), ptr(out)
+    d.scale, d.shift, d.residual = ptr(scale), ptr(shift), ptr(residual)
+    d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = N, Hi, Wi, Ci, Hg, Wg, in_stride
+    _set_taps(d, taps)
+    d.Kfr, d.Ho, d.Wo, d.Co = 1, Ho, Wo, Co
+    d.out_stride, d.out_oy, d.out_ox, d.ldo, d.ldr = out_stride, out_oy, out_ox, ldo, ldr
+    d.flags = (EPI_AFFINE if (scale is not None or shift is not None) else 0) | (EPI_LEAKY if leaky else 0) | \
+              (EPI_RESIDUAL if residual is not None else 0) | (MATH_NOHALO if nohalo else 0)
+    d.slope, d.stats_part = slope, ptr(stats_part)
+    check(_lib().vd_conv_igemm_bf16(C.byref(d), 1 if out.dtype == torch.float32 else 0, _s()), "vd_conv_igemm_bf16")
+    return d
+
+
+def conv_bf16_mtiles(N, Hg, Wg, Ci, Co, tile=0):
+    d = ConvDesc()
+    d.N, d.Hg, d.Wg, d.Ci, d.Co, d.tile = N, Hg, Wg, Ci, Co, tile
+    return _lib().vd_conv_igemm_bf16_mtiles(C.byref(d))
+
+
+def pack_weight_bf16(wp32, wb, *, Co, Co_pad, Ci, Ci_pad, T):
+    """fp32 packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero-padded rows / channels)."""
+    check(_lib().vd_pack_weight_bf16(ptr(wp32), ptr(wb), Co, Co_pad, Ci, Ci_pad, T, _s()), "vd_pack_weight_bf16")
+
+
 def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, splits=0, split=False, amax_in=None,
                amax_dout=None, in_scale=None, in_shift=None, in_slope=0.1):
     """dwp [Co][T*Ci] (fwd-packed layout) = wgrad(x [N,Hi,Wi,Ci], dout [N,Ho,Wo,Co])."""
@@ -148,6 +178,9 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
         d.amax_in, d.amax_dout = ptr(amax_in), ptr(amax_dout)
     else:
         d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
+    if x.dtype == torch.bfloat16:               # bf16-storage training: both operands bf16, the gradient fp32
+        assert dout.dtype == torch.bfloat16 and dwp.dtype == torch.float32
+        d.flags = L.STORE_BF16 | MATH_BF16
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
     if need > ws.numel() * ws.element_size():
@@ -215,13 +248,13 @@ def stem_conv(x_nchw, wp, out, *, scale=None, shift=None, leaky=False, slope=0.1
 def stem_wgrad(x_nchw, dz, dwp, ws):
     """Weight gradient of the stem: dwp [32][32] fwd-packed from x (N,3,H,W) and dz [N,H,W,ldd]."""
     N, _, H, W = x_nchw.shape
-    check(_lib().vd_stem_wgrad(ptr(x_nchw), ptr(dz), dz.shape[-1], ptr(dwp), N, H, W, ptr(ws),
-                               ws.numel() * ws.element_size(), _s()), "vd_stem_wgrad")
+    fn = _lib().vd_stem_wgrad_bf16 if dz.dtype == torch.bfloat16 else _lib().vd_stem_wgrad
+    check(fn(ptr(x_nchw), ptr(dz), dz.shape[-1], ptr(dwp), N, H, W, ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_stem_wgrad")
 
 
 def bn_stats(x2d_rows, C_, x, sums, ws):
-    check(_lib().vd_bn_stats(ptr(x), x2d_rows, C_, ptr(sums), ptr(ws), ws.numel() * ws.element_size(), _s()),
-          "vd_bn_stats")
+    fn = _lib().vd_bn_stats_bf16 if x.dtype == torch.bfloat16 else _lib().vd_bn_stats
+    check(fn(ptr(x), x2d_rows, C_, ptr(sums), ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_bn_stats")
 
 
 def bn_stats_ws_bytes(M, C_):
@@ -239,11 +272,19 @@ def bn_fold_eval(gamma, beta, rmean, rvar, eps, scale, shift):
 
 
 def bn_apply_leaky(x, scale, shift, residual, y, M, C_, slope=0.1, amax_out=None):
+    if x.dtype == torch.bfloat16:
+        check(_lib().vd_bn_apply_leaky_bf16(ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(y), M, C_, slope, _s()),
+              "vd_bn_apply_leaky_bf16")
+        return
     check(_lib().vd_bn_apply_leaky(ptr(x), ptr(scale), ptr(shift), ptr(residual), ptr(y), M, C_, slope, ptr(amax_out),
                                    _s()), "vd_bn_apply_leaky")
 
 
 def bn_bwd_reduce(x, dy, scale, shift, smean, sinv, M, C_, sums2, ws, slope=0.1):
+    if x.dtype == torch.bfloat16:
+        check(_lib().vd_bn_bwd_reduce_bf16(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), M, C_, slope,
+                                           ptr(sums2), ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_bn_bwd_reduce_bf16")
+        return
     check(_lib().vd_bn_bwd_reduce(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), M, C_, slope,
                                   ptr(sums2), ptr(ws), ws.numel() * ws.element_size(), _s()), "vd_bn_bwd_reduce")
 
@@ -253,6 +294,10 @@ def bn_param_grads(sums2, C_, dgamma, dbeta):
 
 
 def bn_bwd_apply(x, dy, scale, shift, smean, sinv, sums2, count, M, C_, dx, slope=0.1, amax_out=None):
+    if x.dtype == torch.bfloat16:
+        check(_lib().vd_bn_bwd_apply_bf16(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), ptr(sums2),
+                                          float(count), M, C_, slope, ptr(dx), _s()), "vd_bn_bwd_apply_bf16")
+        return
     check(_lib().vd_bn_bwd_apply(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), ptr(sums2),
                                  float(count), M, C_, slope, ptr(dx), ptr(amax_out), _s()), "vd_bn_bwd_apply")
 
@@ -273,6 +318,9 @@ def amax_value(slots):
 
 
 def add(a, b, out):
+    if out.dtype == torch.bfloat16:
+        check(_lib().vd_add_bf16(ptr(a), ptr(b), ptr(out), out.numel(), _s()), "vd_add_bf16")
+        return
     check(_lib().vd_add(ptr(a), ptr(b), ptr(out), out.numel(), _s()), "vd_add")
 
 
@@ -283,12 +331,18 @@ def fill(t, v):
 def upsample2x_concat(up, route, out):
     N, Ho, Wo, Cr = route.shape
     Cu = up.shape[3]
+    if out.dtype == torch.bfloat16:             # a copy: two bf16 = one 4-byte word
+        Cu, Cr = Cu // 2, Cr // 2
     check(_lib().vd_upsample2x_concat(ptr(up), ptr(route), ptr(out), N, Ho, Wo, Cu, Cr, _s()), "vd_upsample2x_concat")
 
 
 def upsample2x_concat_bwd(dout, dup, droute):
     N, Ho, Wo, Cr = droute.shape
     Cu = dup.shape[3]
+    if dout.dtype == torch.bfloat16:
+        check(_lib().vd_upsample2x_concat_bwd_bf16(ptr(dout), ptr(dup), ptr(droute), N, Ho, Wo, Cu, Cr, _s()),
+              "vd_upsample2x_concat_bwd_bf16")
+        return
     check(_lib().vd_upsample2x_concat_bwd(ptr(dout), ptr(dup), ptr(droute), N, Ho, Wo, Cu, Cr, _s()),
           "vd_upsample2x_concat_bwd")
 
@@ -343,6 +397,12 @@ def nms_topk(h, cand_score, cand_row, cap, counts, nms_thresh, topk, post_nms, i
 def yolo_loss_fwd_bwd(h, gt, M, obj_t, center_t, scale_t, weight_t, class_t, ignore_thresh, label_smooth, losses,
                       dheads, box_out, ws, dhead_amax=None):
     arr = (C.c_void_p * 3)(*[t.data_ptr() for t in dheads])
+    if dheads[0].dtype == torch.bfloat16:       # bf16-storage training: bf16 gradient rows (fp32 logits)
+        check(_lib().vd_yolo_loss_fwd_bwd_bf16(C.byref(h), ptr(gt), M, ptr(obj_t), ptr(center_t), ptr(scale_t), ptr(weight_t),
+                                               ptr(class_t), ignore_thresh, 1 if label_smooth else 0, ptr(losses),
+                                               C.byref(arr), ptr(box_out), ptr(ws), ws.numel() * ws.element_size(), _s()),
+              "vd_yolo_loss_fwd_bwd_bf16")
+        return
     am = None if dhead_amax is None else C.byref((C.c_void_p * 3)(*[t.data_ptr() for t in dhead_amax]))
     check(_lib().vd_yolo_loss_fwd_bwd(C.byref(h), ptr(gt), M, ptr(obj_t), ptr(center_t), ptr(scale_t), ptr(weight_t),
                                       ptr(class_t), ignore_thresh, 1 if label_smooth else 0, ptr(losses),
