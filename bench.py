@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-native", action="store_true", help="skip the VD_FP32_MATH=native sub-line of the training bench")
     ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = bf16 storage/MFMA inference (detect mode only)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="training only: bf16 = bf16 activations and gradients (net.set_storage('bf16'); BASELINE configs[4])")
     ap.add_argument("--graphs", action="store_true", help="replay the inference program as a captured HIP graph")
     ap.add_argument("--window", type=int, default=1, help="frames per sample (k); 3 with the join flags = BASELINE configs[3]")
     ap.add_argument("--k-join-type", default="max", choices=["max", "mean", "cat"])
@@ -109,7 +111,10 @@ def main():
     # He init keeps synthetic activations O(1); objectness bias negative so only a few % of the C*P score rows
     # pass valid_thresh, as with a trained net.  Same seed on every rank => identical replicas.
     net.initialize(init="he", seed=233, obj_bias=-4.0)
-    if a.dtype == "bf16":
+    if train and a.storage == "bf16":
+        a.dtype = "bf16"
+        net.set_storage("bf16")
+    elif a.dtype == "bf16":
         if train:
             # mixed-precision training arithmetic (BASELINE configs[4] family): fp32 tensors, accumulation and optimiser;
             # convolution products on bf16-rounded operands (VD_MATH_BF16).  NOT the configs[2] headline, which is fp32.
@@ -230,7 +235,9 @@ def main():
             net._refresh_dgrad(tp)
             for seg in tp["fwd"] + tp["bwd"]:
                 if hasattr(seg, "run_timed"):
-                    recs += seg.run_timed({"vd_conv_igemm", "vd_conv_wgrad", "vd_bn_apply_leaky"})
+                    got = seg.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16", "vd_conv_wgrad", "vd_bn_apply_leaky", "vd_bn_apply_leaky_bf16"})
+                    recs += [({"vd_conv_igemm_bf16": "vd_conv_igemm", "vd_bn_apply_leaky_bf16": "vd_bn_apply_leaky"}.get(f_, f_), m, e0, e1)
+                             for (f_, m, e0, e1) in got]
                 else:
                     seg()
         else:
@@ -288,7 +295,9 @@ def main():
         ach = ig[0] / (ig[1] * 1e-3) / 1e12
         if a.dtype == "bf16":
             peak = PEAK_BF16_MFMA_TFLOPS
-            kname = ("k_conv_igemm (fp32 tensors, one bf16 MFMA term per product block)" if train else
+            kname = ("k_conv_igemm_bf16 (bf16 tensors, v_mfma_f32_32x32x16_bf16, fp32 accumulate; forward + data gradients)"
+                     if (train and a.storage == "bf16") else
+                     "k_conv_igemm (fp32 tensors, one bf16 MFMA term per product block)" if train else
                      "k_conv_igemm_bf16 (v_mfma_f32_32x32x16_bf16)")
             math = None
         else:
@@ -389,10 +398,12 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (("temporal-YOLO (k=%d frame windows) training, %d windows/GPU, %dx%d, fp32, fwd+bwd+"
                                      "SGD-momentum (BASELINE configs[3] family)" % (K, B, S, S)) if (train and K > 1) else
-                                    ("yolo3_darknet53 training, %d classes, batch %d/GPU, %dx%d, bf16 conv products on fp32 tensors "
-                                     "(fp32 accumulate / BN / loss / SGD), fwd+bwd+SGD-momentum (BASELINE configs[4] arithmetic%s)"
-                                     % (C, B, S, S, "; its per-GPU shape" if (C == 285 and S == 608 and B == 32) else
-                                        " on the configs[2] shape" if (C == 80 and S == 416) else "")) if a.dtype == "bf16" else
+                                    ("yolo3_darknet53 training, %d classes, batch %d/GPU, %dx%d, %s "
+                                     "(fp32 accumulate / BN statistics / loss / master weights / SGD), fwd+bwd+SGD-momentum (BASELINE configs[4]%s)"
+                                     % (C, B, S, S, "bf16 STORAGE: activations and gradients bf16, bf16 MFMA" if a.storage == "bf16" else
+                                        "bf16 conv products on fp32 tensors",
+                                        "; its per-GPU shape" if (C == 285 and S == 608 and B == 32) else
+                                        " arithmetic on the configs[2] shape" if (C == 80 and S == 416) else " arithmetic")) if a.dtype == "bf16" else
                                     "yolo3_darknet53_coco training, batch %d/GPU, %dx%d, fp32, fwd+bwd+SGD-momentum "
                                     "(BASELINE configs[2]; the reference trains with SGD, not Adam)" % (B, S, S)) if train
                        else ("yolo3_darknet53 inference (detect_yolo3.py path), batch %d/GPU, %dx%d, %s" % (B, S, S, a.dtype)),

@@ -206,3 +206,86 @@ def test_loss_gradient_rows_in_bf16_and_stem_weight_gradient():
     ops.stem_wgrad(x, dz.float(), d2, wsz)
     torch.cuda.synchronize()
     assert torch.equal(d1, d2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the network in bf16 storage (net.set_storage('bf16'))
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_compare(net, P, c, x, gt, tg, out, loss_tol, whole_min, mean_min):
+    from oracle import net as ON
+    onet = ON.Net(P, c)
+    losses_r, G, _ = onet.train_step(x.astype(np.float64), gt, *tg)
+    for i in range(4):
+        got = out[i].cpu().numpy()
+        assert np.all(np.abs(got - losses_r[i]) <= loss_tol * np.maximum(1.0, np.abs(losses_r[i]))), (i, got, losses_r[i])
+    cos, dot, ng, nr = [], 0.0, 0.0, 0.0
+    for k in G.keys():
+        g, r_ = net.collect_params()[k].grad().cpu().numpy().ravel().astype(np.float64), G[k].ravel()
+        assert np.all(np.isfinite(g)), k
+        cos.append(float(g @ r_ / (np.linalg.norm(g) * np.linalg.norm(r_) + 1e-30)))
+        dot, ng, nr = dot + float(g @ r_), ng + float(g @ g), nr + float(r_ @ r_)
+    whole = dot / np.sqrt(ng * nr)
+    print("bf16-storage gradients vs the fp64 oracle: whole cosine %.4f, per-tensor mean %.3f min %.3f, norm ratio %.3f" % (
+        whole, np.mean(cos), min(cos), np.sqrt(ng / nr)))
+    assert whole > whole_min and np.mean(cos) > mean_min, (whole, np.mean(cos), min(cos))
+    assert 0.8 < np.sqrt(ng / nr) < 1.25
+
+
+@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (2, 20, 128, 4)])
+def test_training_step_in_bf16_storage_against_the_oracle(cfg):
+    """One training step with bf16 activations and gradients against the fp64 oracle of the fp32 reference arithmetic.
+    Tolerances are those of the bf16-PRODUCT arithmetic (tests/test_model_gpu.py::test_training_step_in_bf16_products:
+    losses 5 %, whole-gradient cosine > 0.9): storing the tensors in bf16 adds one rounding per tensor to the rounding every
+    conv operand already got there.  Every launch of the step must be a bf16-tensor kernel."""
+    from tests.test_model_gpu import _mk_net, _targets
+    b, c, size, m = cfg
+    net, P = _mk_net(c, 6, obj_bias=-1.0)
+    net.set_storage('bf16')
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((b, 3, size, size)).astype(np.float32)
+    gt, tg = _targets(rng, b, c, size, m)
+    out = net(dev(x), dev(gt), *[dev(t) for t in tg])
+    net.backward()
+    torch.cuda.synchronize()
+    tp = net._last_train
+    names = [fn_ for seg in tp['fwd'] + tp['bwd'] if hasattr(seg, 'recs') for (fn_, _, a) in seg.recs if fn_]
+    assert names.count('vd_conv_igemm_bf16') > 140 and 'vd_conv_igemm' not in names and 'vd_bn_apply_leaky' not in names
+    assert all(t.dtype == BF for k, t in tp['bufs'].items() if torch.is_tensor(t) and t.dim() == 4 and k not in net.head_names and k != 'in')
+    _oracle_compare(net, P, c, x, gt, tg, out, 5e-2, 0.9, 0.7)
+    # the optimiser step and a second forward on the moved weights (bf16 weight images are re-packed per step)
+    w0 = net.weights.clone()
+    net.sgd_step(lr=1e-3, momentum=0.9, wd=5e-4, batch_size=b)
+    out2 = net(dev(x), dev(gt), *[dev(t) for t in tg])
+    net.backward()
+    torch.cuda.synchronize()
+    assert not torch.equal(w0, net.weights) and all(bool(torch.isfinite(o).all()) for o in out2)
+    assert float(sum(o.sum() for o in out2)) < float(sum(o.sum() for o in out))     # one SGD step on the same batch lowers the loss
+    # back to fp32 storage: the fp32 plan of the same shape is independent of the bf16 one
+    net.set_storage('fp32')
+    out3 = net(dev(x), dev(gt), *[dev(t) for t in tg])
+    torch.cuda.synchronize()
+    assert ('train', b, size, size) in net._programs and ('train_bf16', b, size, size) in net._programs
+    assert all(bool(torch.isfinite(o).all()) for o in out3)
+
+
+def test_bf16_storage_loop_learns_its_batch():
+    """60 steps on one batch in bf16 storage: the loss falls as in fp32 storage (tests/test_training_loop_gpu.py) and the
+    trained weights find their boxes through the (fp32) inference path."""
+    from tests.test_model_gpu import _mk_net, _targets
+    c, size, B = 4, 128, 4
+    net, P = _mk_net(c, 21, obj_bias=-1.0)
+    net.set_storage('bf16')
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((B, 3, size, size)).astype(np.float32)
+    gt, tg = _targets(rng, B, c, size, 2)
+    xs, gts, tgs = dev(x), dev(gt), [dev(t) for t in tg]
+    hist = []
+    for it in range(60):
+        out = net(xs, gts, *tgs)
+        net.backward()
+        net.sgd_step(lr=1e-3, momentum=0.9, wd=5e-4, batch_size=B)
+        hist.append(float(sum(o.sum() for o in out)))
+    torch.cuda.synchronize()
+    print("bf16-storage summed loss: step 0 %.1f, 10 %.1f, 59 %.1f" % (hist[0], hist[10], hist[-1]))
+    assert np.all(np.isfinite(hist)) and bool(torch.isfinite(net.weights).all())
+    assert hist[10] < 0.8 * hist[0] and hist[-1] < 0.5 * hist[0], (hist[0], hist[10], hist[-1])

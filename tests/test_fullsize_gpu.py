@@ -169,3 +169,25 @@ def test_configs4_combined_classes_608_batch_32_bf16_products():
     finally:
         M.set_conv_math(None)
         M._TUNE_CACHE.clear()
+
+
+def test_configs4_combined_classes_608_batch_32_bf16_storage():
+    """BASELINE configs[4] per-GPU shape in bf16 STORAGE (net.set_storage('bf16')): 285 classes, 608x608, batch 32 - bf16
+    activations and gradients through vd_conv_igemm_bf16 / VD_STORE_BF16 weight gradients.  The frame property holds for
+    bf16 tensors exactly as for fp32 ones (rows are computed independently of their place in a tile); against the batch-1
+    run heads and losses agree to bf16 accuracy (another tile shape rounds a layer's output differently)."""
+    c, size, B = 285, 608, 32
+    net, P = _mk_net(c, 17, obj_bias=-1.0)
+    net.set_storage('bf16')
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((1, 3, size, size)).astype(np.float32)
+    gt, tg = _targets(rng, 1, c, size, 8)
+    outB, dev_, cos = _train_replication(net, x, gt, tg, B, c, min_tensors=150, head_tol=3e-2, loss_tol=5e-2)
+    assert net._last_train.get('storage') == 'bf16'
+    for e, k in dev_:
+        if k.startswith('yolo_outputs.'):
+            assert e < 5e-2, (k, e)
+    assert cos > 0.9, cos
+    net.sgd_step(lr=1e-3, momentum=0.9, wd=5e-4, batch_size=B)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(net.weights).all())

@@ -1912,6 +1912,365 @@ class YOLOV3(object):
         _TUNE_CACHE.save()
         return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=dgrad_packs, ws=ws)
 
+
+    # ------------------------------------------------------------------ bf16-STORAGE training (BASELINE configs[4])
+    def set_storage(self, storage):
+        """Storage type of the TRAINING activations and their gradients: 'fp32' (default: the reference's arithmetic,
+        train_yolov3.py:623-636) or 'bf16' - conv outputs, cell outputs and both gradient families are bf16 tensors, the
+        convolutions run one bf16 MFMA per product block with fp32 accumulation (vd_conv_igemm_bf16 / VD_STORE_BF16),
+        BatchNorm statistics come from the fp32 accumulators; master weights, weight gradients, BatchNorm vectors, head
+        logits, losses and the optimiser stay fp32.  No reference counterpart: judged against the fp32 oracle at a stated
+        bf16 tolerance (tests/test_bf16_train_gpu.py, test_model_gpu.py)."""
+        if storage not in ('fp32', 'bf16'):
+            raise ValueError("storage must be 'fp32' or 'bf16'")
+        if storage == 'bf16' and (self._k > 1 or self.noback or self.temporal_out or getattr(self, 'temporal_side', False)):
+            raise NotImplementedError("bf16-storage training is built for the single-frame yolo3_darknet53 network")
+        self.storage = storage
+
+    def _tune_bf16_desc(self, d, of32):
+        """Tile (and halo / generic loop) of one vd_conv_igemm_bf16 launch record, timed in place; persisted like the others."""
+        import os
+        if os.environ.get("VD_AUTOTUNE", "1") == "0":
+            return
+        lib = L.load()
+        s = L.stream_ptr()
+        base = d.flags & ~L.MATH_NOHALO
+        key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.out_stride, bool(d.stats_part))
+        if key not in _TUNE_CACHE:
+            best, best_t = (0, L.MATH_NOHALO), None
+            tiles = ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
+                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()))
+            halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
+            for c in tiles:
+                for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
+                    d.tile, d.flags = c, base | fl
+                    L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if best_t is None or t < best_t:
+                        best, best_t = (c, fl), t
+            _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
+        d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
+
+    def _build_train_bf16(self, B, H, W):
+        """The training plan of `_build_train` on bf16 activation / gradient tensors (set_storage('bf16')).  Same schedule:
+        forward with the BatchNorm statistics in the conv epilogues, loss, then the fixed reverse pass with the
+        weight-gradient GEMMs on a side stream and the bucketed gradient all-reduce queued behind them."""
+        dev, BFT = self.device, torch.bfloat16
+        lib = L.load()
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(self.process_group)
+        if self.syncbn_scope and world > 1:
+            raise NotImplementedError("SyncBN with bf16 storage is not built")
+        hb = lambda c: c if (c == 32 or c % 64 == 0) else round_up(c, 64)      # head pitch: the data gradient's K dimension
+        # algorithmic bytes of a launch: every operand tensor once, at 2 bytes per element
+        fl = lambda n_, kind: dict(self._flops(n_, B, H, W, kind), bytes=self._flops(n_, B, H, W, kind)['bytes'] / 2)
+        # ---- buffers
+        bufs = {'in': torch.empty(B, 3, H, W, device=dev)}
+        for name, (c, div, ld, fr) in self.tensors.items():
+            if name == 'in':
+                continue
+            if name in self.head_names:
+                bufs[name] = torch.zeros(B, H // div, W // div, hb(ld), device=dev)              # fp32 logits (pad columns stay 0)
+                bufs['d:' + name] = torch.zeros(B, H // div, W // div, hb(ld), dtype=BFT, device=dev)
+            else:
+                bufs[name] = torch.empty(B, H // div, W // div, c, dtype=BFT, device=dev)
+                bufs['d:' + name] = torch.empty(B, H // div, W // div, c, dtype=BFT, device=dev)
+        for n in self.conv_nodes:
+            if n.bn:
+                bufs['z:' + n.dst] = torch.empty_like(bufs[n.dst])
+        mx = max(bufs[n.dst].numel() for n in self.conv_nodes if not n.head)
+        mx = max([mx] + [bufs[h].numel() for h in self.head_names])
+        bufs['dz'], bufs['dz2'], bufs['tmp'] = [torch.empty(mx, dtype=BFT, device=dev) for _ in range(3)]
+        for nm, t in bufs.items():                     # tune on noise, not on zero pages (see _buffers)
+            if torch.is_tensor(t) and nm not in self.head_names and not nm.startswith('d:yolo') and t.dtype == BFT:
+                t.copy_(torch.randn(min(t.numel(), 1 << 22), device=dev).to(BFT).repeat((t.numel() >> 22) + 1)[:t.numel()].view(t.shape))
+        ws_bytes = 1 << 20
+        for n in self.conv_nodes:
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            if n.stem:
+                ws_bytes = max(ws_bytes, int(lib.vd_stem_wgrad_ws_bytes(B, Hi, Wi)))
+            else:
+                wd_ = WgradDesc()
+                wd_.N, wd_.Hi, wd_.Wi, wd_.Ci, wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = B, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.co_pad
+                wd_.in_stride, wd_.Kfr, wd_.flags = n.stride, 1, L.STORE_BF16 | L.MATH_BF16
+                ops._set_taps(wd_, n.taps())
+                ws_bytes = max(ws_bytes, int(lib.vd_conv_wgrad_ws_bytes(C.byref(wd_))))
+            ws_bytes = max(ws_bytes, ops.bn_stats_ws_bytes(B * Ho * Wo, hb(n.co_pad)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        smax = 16
+        for n in self.conv_nodes:
+            if n.bn:
+                smax = max(smax, ((B * (H // n.div_out) * (W // n.div_out) + 63) // 64 + 8) * 2 * n.cout)
+        stats_ws = torch.empty(smax, device=dev)
+
+        packs = []                                     # (kind, node, plan, fp32 scratch, bf16 image, rows, K, K_pad, T)
+        fwd, seg = [], Program()
+        for n in self.nodes:
+            if isinstance(n, UpcatNode):
+                o = bufs[n.dst]
+                seg.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
+                        o.shape[1], o.shape[2], n.cu // 2, n.cr // 2)          # a copy: two bf16 = one 4-byte word
+                continue
+            if not isinstance(n, ConvNode):
+                raise NotImplementedError("bf16-storage training: node type %s" % type(n).__name__)
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            M = B * Ho * Wo
+            if n.stem:
+                z = bufs['z:' + n.dst]
+                nb = lib.vd_stem_conv_blocks(B, H, W)
+                assert nb * 2 * n.cout <= stats_ws.numel()
+                self._add_stem(seg, n, bufs, B, H, W, z, bf16=True, stats=stats_ws.data_ptr())
+                table_rows = nb
+            else:
+                wb = torch.empty(n.co_pad * n.T * n.cin, dtype=BFT, device=dev)
+                packs.append(('fwd', n, None, None, wb, n.co_pad, n.cin, n.cin, n.T))
+                d = ConvDesc()
+                out = bufs[n.dst] if n.head else bufs['z:' + n.dst]
+                d.in_, d.wp, d.out = bufs[n.src].data_ptr(), wb.data_ptr(), out.data_ptr()
+                d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = B, Hi, Wi, n.cin, Ho, Wo, n.stride
+                ops._set_taps(d, n.taps())
+                d.Kfr, d.Ho, d.Wo, d.Co = 1, Ho, Wo, n.co_pad
+                d.out_stride, d.out_oy, d.out_ox, d.slope = 1, 0, 0, LEAKY_SLOPE
+                d.ldo = d.ldr = out.shape[-1]
+                seg.hold(d, wb)
+                if n.head:
+                    d.flags, d.shift = EPI_AFFINE, n.bias.data_ptr()
+                    self._tune_bf16_desc(d, 1)
+                    seg.add('vd_conv_igemm_bf16', C.byref(d), 1, meta=fl(n, 'fwd'))
+                    continue
+                d.stats_part = stats_ws.data_ptr()
+                self._tune_bf16_desc(d, 0)
+                table_rows = lib.vd_conv_igemm_bf16_mtiles(C.byref(d))
+                assert table_rows * 2 * n.cout <= stats_ws.numel(), "stats workspace too small"
+                seg.add('vd_conv_igemm_bf16', C.byref(d), 0, meta=fl(n, 'fwd'))
+                z = out
+            fin = (n.gamma.data_ptr(), n.beta.data_ptr(), BN_EPS, BN_MOMENTUM, n.rmean.data_ptr(), n.rvar.data_ptr(),
+                   n.b_scale.data_ptr(), n.b_shift.data_ptr(), n.b_mean.data_ptr(), n.b_invstd.data_ptr())
+            seg.add('vd_bn_sum_finalize', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), float(M), *fin,
+                    ws.data_ptr(), ws_bytes)
+            res = bufs[n.residual].data_ptr() if n.residual else None
+            seg.add('vd_bn_apply_leaky_bf16', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
+                    bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE,
+                    meta=dict(node=n.name, bytes=2.0 * M * n.cout * (3 if n.residual else 2), single_conv_consumer=False))
+        grids = self._grid(H, W)
+        ldh = bufs[self.head_names[0]].shape[-1]
+        hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, ldh, STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+        slots = dict(gt=Slot(), M=Slot(), obj=Slot(), ctr=Slot(), scl=Slot(), wgt=Slot(), cls=Slot(), smooth=Slot())
+        losses = torch.zeros(B, 4, device=dev)
+        dh = (C.c_void_p * 3)(*[bufs['d:' + h].data_ptr() for h in self.head_names])
+        lws = torch.empty(max(16, ops.yolo_loss_ws_bytes(hd)), dtype=torch.uint8, device=dev)
+        seg.hold(hd, dh, lws)
+        seg.add('vd_yolo_loss_fwd_bwd_bf16', C.byref(hd), slots['gt'], slots['M'], slots['obj'], slots['ctr'], slots['scl'],
+                slots['wgt'], slots['cls'], float(self._ignore_iou_thresh), slots['smooth'], losses.data_ptr(),
+                C.byref(dh), None, lws.data_ptr(), lws.numel())
+        fwd.append(seg)
+
+        # ---- backward (the schedule of _build_train: wgrad GEMMs on a side stream, double-buffered dz scratch, skip
+        # gradients by alias, bucketed all-reduce behind the weight gradients)
+        bwd, seg = [], Program()
+        side = torch.cuda.Stream() if self.overlap_wgrad else None
+        ws_w = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if side is not None else ws
+        dz_bufs, dz_free, n_dz, last_side = [bufs['dz'], bufs['dz2']], [None, None], [0], [None]
+
+        def ev_record(e, on_side):
+            return lambda: e.record(side if on_side else torch.cuda.current_stream())
+
+        def ev_wait(e, on_side):
+            return lambda: (side if on_side else torch.cuda.current_stream()).wait_event(e)
+
+        bucket_hi, bucket_acc = [self.n_weight], [0]
+        written, alias = set(self.head_names), {}
+        tgrad = {t: False for t in self.tensors}
+        for m in self.nodes:
+            if isinstance(m, ConvNode):
+                tgrad[m.dst] = any(self._node_trainable(m)) or tgrad[m.src] or bool(m.residual and tgrad[m.residual])
+            else:
+                tgrad[m.dst] = tgrad[m.up] or tgrad[m.route]
+        wtrain = [m for m in self.conv_nodes if self._node_trainable(m)[0]]
+        first_wtrain = wtrain[0] if wtrain else None
+        ones = torch.ones(2048, device=dev)
+        zeros = torch.zeros(2048, device=dev)
+
+        def materialize(name):
+            if name in alias:
+                src = alias.pop(name)
+                seg.add('vd_bn_apply_leaky_bf16', src.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None,
+                        bufs['d:' + name].data_ptr(), src.numel() // src.shape[-1], src.shape[-1], 1.0)
+
+        def grad_into(name, can_alias=False):
+            if name in written:
+                if not can_alias:
+                    materialize(name)
+                return bufs['d:' + name], True
+            written.add(name)
+            return bufs['d:' + name], False
+
+        for n in reversed(self.nodes):
+            if isinstance(n, UpcatNode):
+                if not tgrad[n.dst]:
+                    continue
+                dout = bufs['d:' + n.dst]
+                dup_p = drt_p = None
+                acc_r = False
+                if tgrad[n.up]:
+                    dup, acc_u = grad_into(n.up)
+                    assert not acc_u
+                    dup_p = dup.data_ptr()
+                if tgrad[n.route]:
+                    drt, acc_r = grad_into(n.route)
+                    drt_p = drt.data_ptr()
+                if acc_r:
+                    tmp = bufs['tmp'][:drt.numel()]
+                    seg.add('vd_upsample2x_concat_bwd_bf16', dout.data_ptr(), dup_p, tmp.data_ptr(), B, dout.shape[1], dout.shape[2],
+                            n.cu, n.cr)
+                    seg.add('vd_add_bf16', drt.data_ptr(), tmp.data_ptr(), drt.data_ptr(), drt.numel())
+                elif dup_p or drt_p:
+                    seg.add('vd_upsample2x_concat_bwd_bf16', dout.data_ptr(), dup_p, drt_p, B, dout.shape[1], dout.shape[2], n.cu, n.cr)
+                continue
+            Hi, Wi = H // n.div_in, W // n.div_in
+            Ho, Wo = H // n.div_out, W // n.div_out
+            M = B * Ho * Wo
+            if not tgrad[n.dst]:
+                continue
+            w_train, v_train = self._node_trainable(n)
+            dy = bufs['d:' + n.dst]
+            assert n.dst in written, n.name
+            materialize(n.dst)
+            slot = 0
+            if n.head:
+                dz, ldd = dy, dy.shape[-1]
+                if getattr(n, 'sums_b', None) is None or n.sums_b.numel() != 2 * ldd:
+                    n.sums_b = torch.zeros(2 * ldd, dtype=torch.float64, device=dev)
+                seg.add('vd_bn_stats_bf16', dz.data_ptr(), M, ldd, n.sums_b.data_ptr(), ws.data_ptr(), ws_bytes)
+                seg.add('vd_bn_param_grads', n.sums_b.data_ptr(), n.co_pad, bufs['tmp'].data_ptr(), n.gbias.data_ptr())
+                # (dgamma slot of the kernel = scratch: bufs['tmp'] is bf16 storage, n.co_pad floats fit in it)
+            else:
+                if n.residual and tgrad[n.residual]:
+                    dres, acc = grad_into(n.residual)
+                    if acc:
+                        seg.add('vd_add_bf16', dres.data_ptr(), dy.data_ptr(), dres.data_ptr(), dy.numel())
+                    else:
+                        alias[n.residual] = dy
+                        if not self.alias_skip_grad:
+                            materialize(n.residual)
+                z = bufs['z:' + n.dst]
+                slot = n_dz[0] % 2
+                n_dz[0] += 1
+                dz, ldd = dz_bufs[slot][:M * n.cout].view(-1, Ho, Wo, n.cout), n.cout
+                seg.add('vd_bn_bwd_reduce_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(), ws.data_ptr(), ws_bytes)
+                seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
+                if side is not None and dz_free[slot] is not None:
+                    seg.add_py(ev_wait(dz_free[slot], False))
+                seg.add('vd_bn_bwd_apply_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), float(M), M, n.cout, LEAKY_SLOPE, dz.data_ptr())
+            if w_train:
+                if n.stem:
+                    wargs = ('vd_stem_wgrad_bf16', bufs['in'].data_ptr(), dz.data_ptr(), n.co_pad, n.gwp.data_ptr(), B, Hi, Wi)
+                else:
+                    wd_ = WgradDesc()
+                    wd_.in_, wd_.dout, wd_.dwp = bufs[n.src].data_ptr(), dz.data_ptr(), n.gwp.data_ptr()
+                    wd_.N, wd_.Hi, wd_.Wi, wd_.Ci = B, Hi, Wi, n.cin
+                    wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, ldd
+                    wd_.in_stride, wd_.Kfr, wd_.splits, wd_.flags = n.stride, 1, 0, L.STORE_BF16 | L.MATH_BF16
+                    ops._set_taps(wd_, n.taps())
+                    seg.hold(wd_)
+                    wargs = ('vd_conv_wgrad', C.byref(wd_))
+                if side is not None:
+                    e_ready, e_done = torch.cuda.Event(), torch.cuda.Event()
+                    seg.add_py(ev_record(e_ready, False))
+                    seg.add_py(ev_wait(e_ready, True))
+                    seg.add(*wargs, ws_w.data_ptr(), ws_bytes, meta=fl(n, 'wgrad'), stream=side)
+                    seg.add_py(ev_record(e_done, True))
+                    seg.hold(e_ready, e_done)
+                    if not n.head:
+                        dz_free[slot] = e_done
+                    last_side[0] = e_done
+                else:
+                    seg.add(*wargs, ws.data_ptr(), ws_bytes, meta=fl(n, 'wgrad'))
+                bucket_acc[0] += n.w_numel
+                if self.bucketed_allreduce and (bucket_acc[0] >= self.bucket_elems or n is first_wtrain or n.stem):
+                    lo, hi = n.w_off, bucket_hi[0]
+                    seg.add_py(self._bucket_launcher(lo, hi, side))
+                    bucket_hi[0], bucket_acc[0] = lo, 0
+            if n.stem or n.src in self.input_tensors or not tgrad[n.src]:
+                continue
+            dsrc, acc = grad_into(n.src, can_alias=True)
+            res_src = alias.pop(n.src) if n.src in alias else dsrc
+            kp = dz.shape[-1]                                   # K dimension of the data gradient (head: the padded pitch)
+            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, 1, 0):
+                assert plan['taps']
+                T = len(plan['taps'])
+                w32 = torch.empty(n.cin * T * n.co_pad, device=dev)
+                wbd = torch.empty(n.cin * T * kp, dtype=BFT, device=dev)
+                packs.append(('dgrad', n, plan, w32, wbd, n.cin, n.co_pad, kp, T))
+                d = ConvDesc()
+                d.in_, d.wp, d.out = dz.data_ptr(), wbd.data_ptr(), dsrc.data_ptr()
+                d.N, d.Hi, d.Wi, d.Ci = B, Ho, Wo, kp
+                d.Hg, d.Wg, d.in_stride = plan['Hg'], plan['Wg'], 1
+                ops._set_taps(d, plan['taps'])
+                d.Kfr, d.Ho, d.Wo, d.Co = 1, Hi, Wi, n.cin
+                d.out_stride, d.out_oy, d.out_ox = n.stride, plan['py'], plan['px']
+                d.ldo = d.ldr = n.cin
+                d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
+                if acc:
+                    d.residual = res_src.data_ptr()
+                seg.hold(d, w32, wbd)
+                self._tune_bf16_desc(d, 0)
+                seg.add('vd_conv_igemm_bf16', C.byref(d), 0, meta=dict(
+                    kind='dgrad', node=n.name, k=n.k, stride=n.stride,
+                    flops=2.0 * n.cin * n.cout * T * plan['Hg'] * plan['Wg'] * B,
+                    bytes=fl(n, 'dgrad')['bytes'] / (n.stride * n.stride)))
+        if side is not None and last_side[0] is not None:
+            seg.add_py(ev_wait(last_side[0], False))
+        seg.hold(ws_w, side, stats_ws, ones, zeros)
+        bwd.append(seg)
+        _TUNE_CACHE.save()
+        return dict(fwd=fwd, bwd=bwd, bufs=bufs, slots=slots, losses=losses, dgrad_packs=[], packs_bf16=packs, ws=ws, storage='bf16')
+
+    def _refresh_train_bf16(self, tp, overlap=False):
+        """bf16 images of the weights (forward layout and every data-gradient tap plan) after the weights moved; on the pack
+        stream beside the forward pass when `overlap` (the forward images are needed first: they are packed first and the
+        main stream waits for them, the data-gradient images only gate backward())."""
+        if tp.get('dgrad_version') == self._weights_version:
+            return
+        lib = L.load()
+
+        def pack(kinds):
+            s_ = L.stream_ptr()
+            for kind, n, plan, w32, wb, rows, K, Kp, T in tp['packs_bf16']:
+                if kind not in kinds:
+                    continue
+                if kind == 'fwd':
+                    L.check(lib.vd_pack_weight_bf16(n.wp.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
+                else:
+                    ops.pack_weight_dgrad(n.wp, w32, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=1, kh=n.k, kw=n.k,
+                                          tap_ids=plan['tap_ids'], src_packed=True)
+                    L.check(lib.vd_pack_weight_bf16(w32.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
+        pack(('fwd',))
+        ev = None
+        if overlap and self.overlap_wgrad:
+            if self._pack_stream is None:
+                self._pack_stream = torch.cuda.Stream()
+            self._pack_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pack_stream):
+                pack(('dgrad',))
+                ev = torch.cuda.Event()
+                ev.record(self._pack_stream)
+        else:
+            pack(('dgrad',))
+        self._pack_event = ev
+        tp['dgrad_version'] = self._weights_version
+
     @staticmethod
     def _flops(n, B, H, W, kind):
         """Algorithmic FLOPs of one conv launch: 2*Cin*Cout*k*k*Ho*Wo per image."""
@@ -1934,6 +2293,8 @@ class YOLOV3(object):
     def _refresh_dgrad(self, tp, overlap=False):
         """Re-pack the data-gradient weight layout after the weights moved. With overlap=True (start of a training
         step) the 72 small pack launches run on a side stream beside the forward pass; backward() waits on the event."""
+        if tp.get('storage') == 'bf16':
+            return self._refresh_train_bf16(tp, overlap)
         if tp.get('dgrad_version') == self._weights_version:
             return
         ev = None
@@ -2004,11 +2365,12 @@ class YOLOV3(object):
 
     def _forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
         B, H, W = self._in_shape(x)
-        key = ('train', B, H, W)
+        bf16s = getattr(self, 'storage', 'fp32') == 'bf16'
+        key = ('train_bf16' if bf16s else 'train', B, H, W)
         if key not in self._programs:
             # every input shape owns its plan and buffers (random-shape training visits ten); when the next one does not
             # fit beside the others, drop those and build again - their kernel choices stay in the tuning cache
-            self._programs[key] = self._build_or_evict(lambda: self._build_train(B, H, W))
+            self._programs[key] = self._build_or_evict(lambda: (self._build_train_bf16 if bf16s else self._build_train)(B, H, W))
         tp = self._programs[key]
         f32 = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         gt, obj, ctr, scl, wgt, cls = [f32(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
