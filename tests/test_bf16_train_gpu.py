@@ -253,13 +253,13 @@ def test_training_step_in_bf16_storage_against_the_oracle(cfg):
     assert all(t.dtype == BF for k, t in tp['bufs'].items() if torch.is_tensor(t) and t.dim() == 4 and k not in net.head_names and k != 'in')
     _oracle_compare(net, P, c, x, gt, tg, out, 5e-2, 0.9, 0.7)
     # the optimiser step and a second forward on the moved weights (bf16 weight images are re-packed per step)
-    w0 = net.weights.clone()
+    w0, first = net.weights.clone(), float(sum(o.sum() for o in out))      # (the loss tensors are views of the plan's buffer)
     net.sgd_step(lr=1e-3, momentum=0.9, wd=5e-4, batch_size=b)
     out2 = net(dev(x), dev(gt), *[dev(t) for t in tg])
     net.backward()
     torch.cuda.synchronize()
     assert not torch.equal(w0, net.weights) and all(bool(torch.isfinite(o).all()) for o in out2)
-    assert float(sum(o.sum() for o in out2)) < float(sum(o.sum() for o in out))     # one SGD step on the same batch lowers the loss
+    assert float(sum(o.sum() for o in out2)) < first                         # one SGD step on the same batch lowers the loss
     # back to fp32 storage: the fp32 plan of the same shape is independent of the bf16 one
     net.set_storage('fp32')
     out3 = net(dev(x), dev(gt), *[dev(t) for t in tg])
