@@ -1346,6 +1346,7 @@ int dispatch_igemm(const vd_conv_desc& d, hipStream_t s) {
 //   Tiles <WM,WN,TM,TN>: 128x128 (2,2,2,2), 64x128 (2,2,1,2), 32x128 (1,4,1,1) by Co.
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_BN = 128, WG_BP = 32;
+constexpr int WG_BP_BF = 64;      // pixels per K-step of the bf16-tensor form (VD_STORE_BF16)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1373,27 +1374,30 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* plane, int pitch, int c
 
 // second launch bound = waves per SIMD the kernel must fit: two workgroups per CU for the fp32-MFMA tiles (the
 // 8-wave ones must stay within 128 VGPRs), one 8-wave workgroup for the split-math tiles
-// BF (VD_STORE_BF16, bf16-storage training): `in` and `dout` are bf16 tensors - a lane's four channels are one 8-byte
-// load that goes to the (single) LDS plane untouched; the weight gradient itself stays fp32.
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, int NPL = 3, bool BF = false>
+// BF (VD_STORE_BF16, bf16-storage training): `in` and `dout` are bf16 tensors - a lane's EIGHT channels are one 16-byte
+// load that goes to the (single) LDS plane untouched, and a K-step is BP = 64 pixels (the same bytes per step and twice the
+// MFMAs per barrier of the fp32-tensor form: with one MFMA term per product the 32-pixel step was barrier-bound, 378 TF);
+// the weight gradient itself stays fp32.
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, int NPL = 3, bool BF = false, int BP = WG_BP>
 __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * WN / 2)) void k_conv_wgrad(const vd_wgrad_desc p, float* __restrict__ dst,
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
     static_assert(!BF || (SP && NPL == 1 && !XF), "bf16-stored operands: one plane, no in-load transform");
-    using LT = typename vd_select<BF, uint2, f32x4>::type;      // what a lane holds of one (pixel, 4 channels)
+    using LT = typename vd_select<BF, uint4, f32x4>::type;      // what a lane holds of one (pixel, VW channels)
+    constexpr int VW = BF ? 8 : 4;            // channels per lane and load
     constexpr int BM = WM * TM * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
     static_assert(WN * TN * 32 == WG_BN && (WM * WN == 4 || WM * WN == 8), "tile");
-    constexpr int AROWS = NT * 4 / BM;        // pixel rows of the dout tile one pass of NT float4 lanes covers
-    constexpr int APASS = WG_BP / AROWS;
-    constexpr int BROWS = NT * 4 / WG_BN;
-    constexpr int BPASS = WG_BP / BROWS;
+    constexpr int AROWS = NT * VW / BM;       // pixel rows of the dout tile one pass of NT 16-byte lanes covers
+    constexpr int APASS = BP / AROWS;
+    constexpr int BROWS = NT * VW / WG_BN;
+    constexpr int BPASS = BP / BROWS;
     static_assert(APASS >= 1 && BPASS >= 1, "loader");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][WG_BP][BM]      dout
-    float* Bs = smem + 2 * WG_BP * BM;        // [2][WG_BP][WG_BN]   in
+    float* Bs = smem + 2 * BP * BM;           // [2][BP][WG_BN]   in
     // SP: bf16 planes h/m/l, pixel-major, [2 stages][3][WG_BP][BM] then [2][3][WG_BP][WG_BN]
-    constexpr int APL = WG_BP * BM * 2, BPL = WG_BP * WG_BN * 2;      // bytes of one plane
+    constexpr int APL = BP * BM * 2, BPL = BP * WG_BN * 2;            // bytes of one plane
     char* As3 = reinterpret_cast<char*>(smem);
     char* Bs3 = As3 + 2 * NPL * APL;
     constexpr int NTERM = Terms<NPL>::N;
@@ -1427,8 +1431,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     if (p_end > P) p_end = P;
 
     // B operand: this thread's column chunk -> (tap, channel), fixed for the whole reduction
-    const int blpix = tid / (WG_BN / 4);
-    const int blc = (tid % (WG_BN / 4)) * 4;
+    const int blpix = tid / (WG_BN / VW);
+    const int blc = (tid % (WG_BN / VW)) * VW;
     const int j = tile_j * WG_BN + blc;
     const bool j_ok = j < Ktot;
     const int tap = j_ok ? j / p.Ci : 0;
@@ -1436,8 +1440,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     const int dy = p.dy[tap], dx = p.dx[tap], dz = p.dz[tap];
     const int64_t boff = (int64_t)((dz * p.Hi + dy) * p.Wi + dx) * p.Ci + ci;
     // A operand (dout)
-    const int alpix = tid / (BM / 4);
-    const int alc = (tid % (BM / 4)) * 4;
+    const int alpix = tid / (BM / VW);
+    const int alc = (tid % (BM / VW)) * VW;
     const int co = tile_m * BM + alc;
     const bool co_ok = co < p.Co;             // Co, Ci multiples of 4 => whole float4 in or out
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -1459,7 +1463,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
         cgy[i] = (int)(t - n_ * (unsigned)p.Hg);
         cn[i] = (int)n_;
     }
-    const int step_x = WG_BP % p.Wg, step_y = WG_BP / p.Wg;
+    const int step_x = BP % p.Wg, step_y = BP / p.Wg;
     const bool one_wrap = (step_y + 1) <= p.Hg;     // at most one image boundary per step (true unless the map is tiny)
 
     f32x16 acc[TM][TN];
@@ -1476,13 +1480,13 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     int64_t next_p = p_begin;                 // first pixel of the next tile to request
     auto gload = [&](LT (&ra)[APASS], LT (&rb)[BPASS]) {
         const int64_t pbase = next_p;
-        next_p += WG_BP;
+        next_p += BP;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int64_t pix = pbase + alpix + AROWS * i;
             const bool ok = pix < p_end && co_ok;
             const int64_t sel = ok ? pix * p.ldd + co : zd_do;
-            if constexpr (BF) ra[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
+            if constexpr (BF) ra[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
             else ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
         }
 #pragma unroll
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const int64_t o = (int64_t)((n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride) * p.Ci + boff;
             const int64_t sel = bok ? o : zd_in;
             if constexpr (BF) {
-                rb[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.in) + sel);
+                rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.in) + sel);
             } else {
                 f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + sel);
                 if (XF) {
@@ -1509,7 +1513,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                 }
                 rb[i] = vb;
             }
-            // advance the cursor by WG_BP pixels
+            // advance the cursor by BP pixels
             int nx = gx + step_x, ny = gy + step_y;
             if (nx >= p.Wg) { nx -= p.Wg; ++ny; }
             int nn = n;
@@ -1529,12 +1533,12 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 const int px = alpix + AROWS * i;
-                *reinterpret_cast<uint2*>(a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6)) = ra[i];
+                *reinterpret_cast<uint4*>(a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6)) = ra[i];
             }
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 const int px = blpix + BROWS * i;
-                *reinterpret_cast<uint2*>(b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6)) = rb[i];
+                *reinterpret_cast<uint4*>(b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6)) = rb[i];
             }
             return;
         } else if constexpr (SP) {
@@ -1576,8 +1580,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             }
             return;
         } else {
-            float* a = As + buf * WG_BP * BM;
-            float* bb = Bs + buf * WG_BP * WG_BN;
+            float* a = As + buf * BP * BM;
+            float* bb = Bs + buf * BP * WG_BN;
 #pragma unroll
             for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + (alpix + AROWS * i) * BM + alc) = ra[i];
 #pragma unroll
@@ -1589,7 +1593,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const char* a3 = As3 + buf * NPL * APL;
             const char* b3 = Bs3 + buf * NPL * BPL;
 #pragma unroll
-            for (int kc = 0; kc < WG_BP / 16; ++kc) {
+            for (int kc = 0; kc < BP / 16; ++kc) {
                 v4i fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
@@ -1610,10 +1614,10 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             }
             return;
         }
-        const float* a = As + buf * WG_BP * BM + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
-        const float* bb = Bs + buf * WG_BP * WG_BN + (lane >> 5) * WG_BN + wn * TN * 32 + (lane & 31);
+        const float* a = As + buf * BP * BM + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
+        const float* bb = Bs + buf * BP * WG_BN + (lane >> 5) * WG_BN + wn * TN * 32 + (lane & 31);
 #pragma unroll
-        for (int kk = 0; kk < WG_BP / 2; ++kk) {
+        for (int kk = 0; kk < BP / 2; ++kk) {
             float fa[TM], fb[TN];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) fa[mi] = a[kk * 2 * BM + mi * 32];
@@ -1628,7 +1632,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
     };
 
     // same pipeline as k_conv_igemm: PD register sets, branch-free steady state, guarded tail
-    const int nks = (p_end > p_begin) ? (int)vd_cdiv(p_end - p_begin, WG_BP) : 0;
+    const int nks = (p_end > p_begin) ? (int)vd_cdiv(p_end - p_begin, BP) : 0;
     constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;
     if (nks > 0) {
         gload(ra[0], rb[0]);
@@ -1750,8 +1754,8 @@ int wgrad_pick_splits(const vd_wgrad_desc& d) {
 template <int WM, int WN, int TM, int TN>
 void launch_wgrad_bf(const vd_wgrad_desc& d, float* dst, int splits, int64_t pps, hipStream_t s) {
     constexpr int BM = WM * TM * 32;
-    constexpr int lds = 2 * WG_BP * (BM + WG_BN) * 2;
-    auto kfn = k_conv_wgrad<WM, WN, TM, TN, false, true, 1, true>;
+    constexpr int lds = 2 * WG_BP_BF * (BM + WG_BN) * 2;
+    auto kfn = k_conv_wgrad<WM, WN, TM, TN, false, true, 1, true, WG_BP_BF>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1952,7 +1956,8 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t P = (int64_t)d->N * d->Hg * d->Wg;
-    int64_t pps = vd_cdiv(vd_cdiv(P, splits), WG_BP) * WG_BP;
+    const int bp = (d->flags & VD_STORE_BF16) ? WG_BP_BF : WG_BP;
+    int64_t pps = vd_cdiv(vd_cdiv(P, splits), bp) * bp;
     float* dst = (splits > 1) ? (float*)ws : d->dwp;
     const int bm = wgrad_bm(*d);
     if (d->flags & VD_STORE_BF16) {

@@ -2012,6 +2012,10 @@ class YOLOV3(object):
         stats_ws = torch.empty(smax, device=dev)
 
         packs = []                                     # (kind, node, plan, fp32 scratch, bf16 image, rows, K, K_pad, T)
+        # forward images: the conv weights live fwd-packed [co_pad][T * Ci] in the arena and need no padding here (every Ci
+        # is 32 or a multiple of 64), so ONE conversion of the arena's weight range makes all of them
+        wb_arena = torch.empty(self.n_weight, dtype=BFT, device=dev)
+        packs.append(('arena', None, None, None, wb_arena, 1, self.n_weight, self.n_weight, 1))
         fwd, seg = [], Program()
         for n in self.nodes:
             if isinstance(n, UpcatNode):
@@ -2031,8 +2035,8 @@ class YOLOV3(object):
                 self._add_stem(seg, n, bufs, B, H, W, z, bf16=True, stats=stats_ws.data_ptr())
                 table_rows = nb
             else:
-                wb = torch.empty(n.co_pad * n.T * n.cin, dtype=BFT, device=dev)
-                packs.append(('fwd', n, None, None, wb, n.co_pad, n.cin, n.cin, n.T))
+                wb = wb_arena[n.w_off:n.w_off + n.w_numel]
+                assert n.w_numel == n.co_pad * n.T * n.cin and n.w_off % 8 == 0
                 d = ConvDesc()
                 out = bufs[n.dst] if n.head else bufs['z:' + n.dst]
                 d.in_, d.wp, d.out = bufs[n.src].data_ptr(), wb.data_ptr(), out.data_ptr()
@@ -2250,13 +2254,13 @@ class YOLOV3(object):
             for kind, n, plan, w32, wb, rows, K, Kp, T in tp['packs_bf16']:
                 if kind not in kinds:
                     continue
-                if kind == 'fwd':
-                    L.check(lib.vd_pack_weight_bf16(n.wp.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
+                if kind == 'arena':
+                    L.check(lib.vd_pack_weight_bf16(self.weights.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
                 else:
                     ops.pack_weight_dgrad(n.wp, w32, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=1, kh=n.k, kw=n.k,
                                           tap_ids=plan['tap_ids'], src_packed=True)
                     L.check(lib.vd_pack_weight_bf16(w32.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
-        pack(('fwd',))
+        pack(('arena',))
         ev = None
         if overlap and self.overlap_wgrad:
             if self._pack_stream is None:
