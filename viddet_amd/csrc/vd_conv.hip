@@ -1383,7 +1383,8 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
                                                              int splits, int64_t pix_per_split, const int64_t zd_in,
                                                              const int64_t zd_do) {
     static_assert(!BF || (SP && NPL == 1 && !XF), "bf16-stored operands: one plane, no in-load transform");
-    using LT = typename vd_select<BF, uint4, f32x4>::type;      // what a lane holds of one (pixel, VW channels)
+    using LT = typename vd_select<BF, v4i, f32x4>::type;        // what a lane holds of one (pixel, VW channels): ext vectors (a
+                                                                // struct type such as uint4 sent the register sets to scratch)
     constexpr int VW = BF ? 8 : 4;            // channels per lane and load
     constexpr int BM = WM * TM * 32;
     constexpr int NT = WM * WN * 64;          // 4 or 8 waves
@@ -1486,7 +1487,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const int64_t pix = pbase + alpix + AROWS * i;
             const bool ok = pix < p_end && co_ok;
             const int64_t sel = ok ? pix * p.ldd + co : zd_do;
-            if constexpr (BF) ra[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
+            if constexpr (BF) ra[i] = *reinterpret_cast<const v4i*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
             else ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
         }
 #pragma unroll
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
             const int64_t o = (int64_t)((n * p.Hi + gy * p.in_stride) * p.Wi + gx * p.in_stride) * p.Ci + boff;
             const int64_t sel = bok ? o : zd_in;
             if constexpr (BF) {
-                rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(p.in) + sel);
+                rb[i] = *reinterpret_cast<const v4i*>(reinterpret_cast<const __bf16*>(p.in) + sel);
             } else {
                 f32x4 vb = *reinterpret_cast<const f32x4*>(p.in + sel);
                 if (XF) {
@@ -1533,12 +1534,12 @@ __global__ __launch_bounds__(WM * WN * 64, (SP ? (TM * TN == 1 ? 4 : 2) : WM * W
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 const int px = alpix + AROWS * i;
-                *reinterpret_cast<uint4*>(a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6)) = ra[i];
+                *reinterpret_cast<v4i*>(a3 + px * (BM * 2) + (((alc >> 5) ^ sp_key(px, BM * 2)) << 6)) = ra[i];
             }
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
                 const int px = blpix + BROWS * i;
-                *reinterpret_cast<uint4*>(b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6)) = rb[i];
+                *reinterpret_cast<v4i*>(b3 + px * (WG_BN * 2) + (((blc >> 5) ^ sp_key(px, WG_BN * 2)) << 6)) = rb[i];
             }
             return;
         } else if constexpr (SP) {
