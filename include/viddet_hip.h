@@ -381,6 +381,8 @@ int vd_bn_bwd_reduce_bf16(const void* x, const void* dy, const float* scale, con
 int vd_bn_bwd_apply_bf16(const void* x, const void* dy, const float* scale, const float* shift, const float* save_mean,
                          const float* save_invstd, const double* sums2, double count, int64_t M, int C, float slope,
                          void* dx, void* stream);
+int vd_pack_weight_dgrad_bf16(const float* w, void* wp_bf16, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
+                              const int32_t* taps, int ntaps, int src_packed, void* stream);
 int vd_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 int vd_upsample2x_concat_bwd_bf16(const void* dout, void* dup, void* droute, int N, int Ho, int Wo, int Cu, int Cr, void* stream);
 int vd_stem_wgrad_bf16(const float* x_nchw, const void* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,

@@ -1820,7 +1820,8 @@ __global__ void k_pack_fwd(const float* __restrict__ w, float* __restrict__ wp, 
 
 struct TapList { int v[VD_MAX_TAPS]; };
 
-__global__ void k_pack_dgrad(const float* __restrict__ w, float* __restrict__ wp, int Co, int Co_pad,
+template <typename OT>      // float, or __bf16 (the images of bf16-storage training)
+__global__ void k_pack_dgrad(const float* __restrict__ w, OT* __restrict__ wp, int Co, int Co_pad,
                              int Ci, int T, const TapList taps, int ntaps, int src_packed) {
     // wp[ci][j*Co_pad + co] = w[co][ci][taps[j]]   (w OIHW, or fwd-packed [co][t*Ci+ci] if src_packed)
     const int64_t total = (int64_t)Ci * ntaps * Co_pad;
@@ -1833,7 +1834,7 @@ __global__ void k_pack_dgrad(const float* __restrict__ w, float* __restrict__ wp
         float v = 0.f;
         if (co < Co)
             v = src_packed ? w[((int64_t)co * T + taps.v[j]) * Ci + ci] : w[((int64_t)co * Ci + ci) * T + taps.v[j]];
-        wp[i] = v;
+        wp[i] = (OT)v;
     }
 }
 
@@ -1996,8 +1997,8 @@ int vd_pack_weight_fwd(const float* w, float* wp, int Co, int Co_pad, int Ci, in
     return VD_OK;
 }
 
-int vd_pack_weight_dgrad(const float* w, float* wp, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
-                         const int32_t* taps, int ntaps, int src_packed, void* stream) {
+static int pack_dgrad_any(const float* w, void* wp, int out_bf16, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
+                          const int32_t* taps, int ntaps, int src_packed, void* stream) {
     VD_REQUIRE(w && wp && taps && ntaps > 0 && ntaps <= VD_MAX_TAPS && Co_pad >= Co, "vd_pack_weight_dgrad: bad args");
     const int T = kd * kh * kw;
     TapList tl;
@@ -2005,9 +2006,25 @@ int vd_pack_weight_dgrad(const float* w, float* wp, int Co, int Co_pad, int Ci, 
     for (int j = 0; j < ntaps; ++j) VD_REQUIRE(taps[j] >= 0 && taps[j] < T, "vd_pack_weight_dgrad: tap index out of range");
     const int64_t total = (int64_t)Ci * ntaps * Co_pad;
     const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
-    hipLaunchKernelGGL(k_pack_dgrad, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Co_pad, Ci, T, tl, ntaps, src_packed);
+    if (out_bf16)
+        hipLaunchKernelGGL(k_pack_dgrad<__bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wp, Co, Co_pad, Ci, T, tl, ntaps,
+                           src_packed);
+    else
+        hipLaunchKernelGGL(k_pack_dgrad<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, (float*)wp, Co, Co_pad, Ci, T, tl, ntaps,
+                           src_packed);
     VD_CHECK_LAUNCH("vd_pack_weight_dgrad");
     return VD_OK;
+}
+
+int vd_pack_weight_dgrad(const float* w, float* wp, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
+                         const int32_t* taps, int ntaps, int src_packed, void* stream) {
+    return pack_dgrad_any(w, wp, 0, Co, Co_pad, Ci, kd, kh, kw, taps, ntaps, src_packed, stream);
+}
+
+/* the same layout as bf16 [Ci][ntaps * Co_pad] (bf16-storage training: Co_pad = the K pitch of the data gradient) */
+int vd_pack_weight_dgrad_bf16(const float* w, void* wp_bf16, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
+                              const int32_t* taps, int ntaps, int src_packed, void* stream) {
+    return pack_dgrad_any(w, wp_bf16, 1, Co, Co_pad, Ci, kd, kh, kw, taps, ntaps, src_packed, stream);
 }
 
 int vd_unpack_wgrad(const float* dwp, float* dw, int Co, int Ci, int kd, int kh, int kw, void* stream) {

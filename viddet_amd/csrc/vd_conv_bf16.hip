@@ -679,6 +679,19 @@ __global__ void k_pack_bf16(const float* __restrict__ src, __bf16* __restrict__ 
     }
 }
 
+// no padding anywhere: a plain fp32 -> bf16 conversion, 8 elements (32 B in, 16 B out) per thread
+__global__ void k_cvt_bf16(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n8, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+    const int64_t t = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // tail (n not a multiple of 8)
+    if (t < n) dst[t] = (__bf16)src[t];
+}
+
 __global__ void k_stem_im2col_bf16(const float* __restrict__ in, __bf16* __restrict__ col, int N, int H, int W, int nchw) {
     // col [N,H,W,64] bf16: entries (ky*3+kx)*3+c for k < 27, zero above
     const int64_t total = (int64_t)N * H * W * 8;          // one 16-byte chunk (8 bf16) per thread
@@ -755,6 +768,13 @@ int vd_debug_stamps(unsigned long long* out) {
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T, void* stream) {
     VD_REQUIRE(wp_f32 && wp_bf16 && Co > 0 && Co_pad >= Co && Ci > 0 && Ci_pad >= Ci && T > 0, "vd_pack_weight_bf16: bad args");
     const int64_t total = (int64_t)Co_pad * T * Ci_pad;
+    if (Co == Co_pad && Ci == Ci_pad && (uintptr_t)wp_f32 % 16 == 0 && (uintptr_t)wp_bf16 % 16 == 0) {
+        const int64_t n8 = total / 8;
+        const int nbv = (int)(vd_cdiv(n8 + 8, 256) < 4096 ? vd_cdiv(n8 + 8, 256) : 4096);
+        hipLaunchKernelGGL(k_cvt_bf16, dim3(nbv), dim3(256), 0, (hipStream_t)stream, wp_f32, (__bf16*)wp_bf16, n8, total);
+        VD_CHECK_LAUNCH("vd_pack_weight_bf16/convert");
+        return VD_OK;
+    }
     const int nb = (int)(vd_cdiv(total, 256) < 4096 ? vd_cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(k_pack_bf16, dim3(nb), dim3(256), 0, (hipStream_t)stream, wp_f32, (__bf16*)wp_bf16, Co, Co_pad, Ci, Ci_pad, T);
     VD_CHECK_LAUNCH("vd_pack_weight_bf16");

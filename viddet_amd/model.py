@@ -2214,7 +2214,7 @@ class YOLOV3(object):
             for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, 1, 0):
                 assert plan['taps']
                 T = len(plan['taps'])
-                w32 = torch.empty(n.cin * T * n.co_pad, device=dev)
+                w32 = None
                 wbd = torch.empty(n.cin * T * kp, dtype=BFT, device=dev)
                 packs.append(('dgrad', n, plan, w32, wbd, n.cin, n.co_pad, kp, T))
                 d = ConvDesc()
@@ -2228,7 +2228,7 @@ class YOLOV3(object):
                 d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
                 if acc:
                     d.residual = res_src.data_ptr()
-                seg.hold(d, w32, wbd)
+                seg.hold(d, wbd)
                 self._tune_bf16_desc(d, 0)
                 seg.add('vd_conv_igemm_bf16', C.byref(d), 0, meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
@@ -2257,9 +2257,9 @@ class YOLOV3(object):
                 if kind == 'arena':
                     L.check(lib.vd_pack_weight_bf16(self.weights.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
                 else:
-                    ops.pack_weight_dgrad(n.wp, w32, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=1, kh=n.k, kw=n.k,
-                                          tap_ids=plan['tap_ids'], src_packed=True)
-                    L.check(lib.vd_pack_weight_bf16(w32.data_ptr(), wb.data_ptr(), rows, rows, K, Kp, T, s_), 'vd_pack_weight_bf16')
+                    arr = (C.c_int32 * T)(*plan['tap_ids'])          # straight to bf16 [cin][T * K pitch]
+                    L.check(lib.vd_pack_weight_dgrad_bf16(n.wp.data_ptr(), wb.data_ptr(), K, Kp, n.cin, 1, n.k, n.k, arr, T, 1, s_),
+                            'vd_pack_weight_dgrad_bf16')
         pack(('arena',))
         ev = None
         if overlap and self.overlap_wgrad:
