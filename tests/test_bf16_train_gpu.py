@@ -64,6 +64,59 @@ def test_data_gradient_through_the_bf16_conv_kernel(shape):
     assert maxdiff(got, ref) < tol, (maxdiff(got, ref), tol)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 13, 13, 128, 3, 1, 1), (2, 64, 18, 20, 128, 3, 2, 1), (2, 128, 9, 11, 64, 1, 1, 0)])
+def test_data_gradient_with_fused_batchnorm_backward_reductions(shape):
+    """vd_conv_desc.bs_*: sum g and sum g * xhat of the layer whose dy the data gradient completes (g = dy * leaky'(z * scale
+    + shift), xhat = (z - mean) * invstd), from the fp32 values of dy before they are rounded to bf16; a stride-2 data
+    gradient adds its four parity launches' table rows."""
+    from viddet_amd import ops, lib as L
+    n, ci, h, w, co, k, s, p = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    wt = _r(rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k))
+    dz = _r(rng.standard_normal((n, co, ho, wo)))
+    skip = _r(rng.standard_normal((n, ci, h, w)))
+    z = _r(rng.standard_normal((n, ci, h, w)) * 1.5)                       # the producer's pre-BatchNorm output
+    scale, shift = rng.uniform(0.5, 1.5, ci), rng.standard_normal(ci) * 0.3
+    mean, invstd = rng.standard_normal(ci) * 0.1, rng.uniform(0.5, 2.0, ci)
+    dy = R.conv2d_backward(np.zeros((n, ci, h, w)), wt, dz, s, p)[0] + skip
+    sh4 = (1, -1, 1, 1)
+    u = z * scale.reshape(sh4) + shift.reshape(sh4)
+    g = np.where(u > 0, dy, 0.1 * dy)
+    ref = np.concatenate([g.sum(axis=(0, 2, 3)), (g * (z - mean.reshape(sh4)) * invstd.reshape(sh4)).sum(axis=(0, 2, 3))])
+    dzd, skd, zd = _nhwc_b(dz), _nhwc_b(skip), _nhwc_b(z)
+    wp32 = torch.empty(co, k * k * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp32, co)
+    out = torch.zeros(n, h, w, ci, dtype=BF, device="cuda")
+    sc, sh, mu, iv = dev(scale), dev(shift), dev(mean), dev(invstd)
+    part = torch.zeros(4096, 2 * ci, device="cuda")
+    rows = 0
+    for pl in ops.dgrad_plans(k, p, s, h, w):
+        T = len(pl["taps"])
+        wpk = torch.empty(ci, T * co, device="cuda")
+        ops.pack_weight_dgrad(wp32, wpk, Co=co, Co_pad=co, Ci=ci, kd=1, kh=k, kw=k, tap_ids=pl["tap_ids"], src_packed=True)
+        wb = torch.empty(ci, T * co, dtype=BF, device="cuda")
+        ops.pack_weight_bf16(wpk, wb, Co=ci, Co_pad=ci, Ci=co, Ci_pad=co, T=T)
+        d = L.ConvDesc()
+        d.in_, d.wp, d.out, d.residual = dzd.data_ptr(), wb.data_ptr(), out.data_ptr(), skd.data_ptr()
+        d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, ho, wo, co, pl["Hg"], pl["Wg"], 1
+        ops._set_taps(d, pl["taps"])
+        d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.out_oy, d.out_ox = 1, h, w, ci, s, pl["py"], pl["px"]
+        d.ldo = d.ldr = ci
+        d.flags, d.slope = L.EPI_RESIDUAL, 0.1
+        d.bs_z, d.bs_scale, d.bs_shift, d.bs_mean, d.bs_invstd = zd.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), iv.data_ptr()
+        d.bs_part, d.bs_slope = part.data_ptr() + rows * 2 * ci * 4, 0.1
+        L.check(L.load().vd_conv_igemm_bf16(C.byref(d), 0, L.stream_ptr()), "vd_conv_igemm_bf16")
+        rows += L.load().vd_conv_igemm_bf16_mtiles(C.byref(d))
+    torch.cuda.synchronize()
+    assert maxdiff(_nchw(out), dy) < 2e-4 + np.abs(dy).max() * EPS
+    got = part[:rows].double().sum(dim=0).cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-4, atol=2e-3 * np.sqrt(n * h * w)), np.abs(got - ref).max()
+    # tile 8 (256 x 256) has no fused form: refused, never silently unreduced
+    d.tile = 8
+    assert L.load().vd_conv_igemm_bf16(C.byref(d), 0, L.stream_ptr()) != 0 and b"tile other than 8" in L.load().vd_last_error()
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 6, 10, 13])
 def test_forward_conv_with_fused_statistics(tile):
     """Training forward: raw bf16 output + the BatchNorm partial sums of the fp32 accumulators (one table row per M tile),

@@ -58,7 +58,10 @@ struct RowInfoB {
 // BM output pixels plus W + 1 pixels either side, 128 B per pixel - and the nine taps read it at row offsets dy * W + dx
 // (rows of taps outside the image read a zero row): (BM + 2 W + 2) / (9 BM) of the gather bytes.  Same scheme as the fp16-split
 // halo loop of vd_conv.hip (there with the rationale and the measurements); here the stream moves bf16 rows untouched.
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR, bool HALO = false>
+// BS (bf16-storage training, data gradients): the fused BatchNorm-backward reductions of vd_conv_igemm (vd_conv_desc.bs_*)
+// in the epilogue - sum g and sum g * xhat of the layer whose dy this launch completes, from the fp32 values before they
+// are rounded to bf16; z (p.bs_z) is a bf16 tensor of the output's geometry.
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR, bool HALO = false, bool BS = false>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
                                                                   const int64_t zd_w) {
     static_assert(!HALO || (WM * WN == 8 && !PAIR), "the halo loop exists for the 8-wave tiles");
@@ -427,6 +430,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
         const int gy = (int)(t - n * (unsigned)p.Hg);
         return ((int64_t)n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
     };
+    float bs_acc1[BS ? TN : 1][4], bs_acc2[BS ? TN : 1][4];      // BS: sum g / sum g * xhat of this lane's columns
+#pragma unroll
+    for (int ni = 0; ni < (BS ? TN : 1); ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs_acc1[ni][e] = bs_acc2[ni][e] = 0.f;
     const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) && (p.Co % 4 == 0) &&
                         (!has_res || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0))) &&
                         (!has_aff || (((uintptr_t)p.scale | (uintptr_t)p.shift) % 16 == 0));
@@ -443,6 +451,33 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
             const int cc = col < p.Co ? col : 0;
             sc[ni] = (has_aff && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + cc) : f32x4{1.f, 1.f, 1.f, 1.f};
             sh[ni] = (has_aff && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const bool bstat = BS && p.bs_part != nullptr;
+        const __bf16* bz = reinterpret_cast<const __bf16*>(p.bs_z);
+        f32x4 qsc[BS ? TN : 1], qsh[BS ? TN : 1], qmu[BS ? TN : 1], qis[BS ? TN : 1];
+        bf16x4 zv[BS ? TM : 1][BS ? TN : 1][4];
+        if (BS) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int cc = colv[ni] < 0 ? 0 : colv[ni];
+                const f32x4 z0 = {0.f, 0.f, 0.f, 0.f};
+                qsc[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_scale + cc) : z0;
+                qsh[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_shift + cc) : z0;
+                qmu[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_mean + cc) : z0;
+                qis[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_invstd + cc) : z0;
+            }
+            if (bstat) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
+                            m = m < M ? m : M - 1;
+                            zv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(bz + out_pix(m) * p.ldo + (colv[ni] < 0 ? 0 : colv[ni]));
+                        }
+            }
         }
         bf16x4 rv[TM][TN][4];
         if (has_res) {
@@ -483,6 +518,18 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
                     if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) t[e] += (float)rv[mi][ni][i][e];
+                    }
+                    if (BS && bstat) {
+                        const bool ok = m < M && colv[ni] >= 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = (float)zv[mi][ni][i][e];
+                            const float u = z * qsc[ni][e] + qsh[ni][e];
+                            float g = u > 0.f ? t[e] : t[e] * p.bs_slope;
+                            g = ok ? g : 0.f;
+                            bs_acc1[ni][e] += g;
+                            bs_acc2[ni][e] += g * (z - qmu[ni][e]) * qis[ni][e];
+                        }
                     }
                     if (m < M && colv[ni] >= 0) {
                         const int64_t op = out_pix(m);
@@ -542,6 +589,42 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
         }
     }
     STAMP(5);
+    // ---- fused BatchNorm backward reductions: one row of the partial table [tile_m][2 * Co] per M tile (as k_conv_igemm)
+    if constexpr (BS) {
+        if (p.bs_part != nullptr) {
+            __syncthreads();        // every wave is done with its staging patch
+            float* red = reinterpret_cast<float*>(smem_b);      // [WM][BN][2]
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = bs_acc1[ni][e], b = bs_acc2[ni][e];
+                    a += __shfl_xor(a, 8);  b += __shfl_xor(b, 8);
+                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                    if (lane < 8) {
+                        const int c = wn * TN * 32 + ni * 32 + ec4 + e;
+                        red[(wm * BN + c) * 2 + 0] = a;
+                        red[(wm * BN + c) * 2 + 1] = b;
+                    }
+                }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                const int colc = tile_n * BN + c;
+                if (colc < p.Co) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        a += red[(w * BN + c) * 2 + 0];
+                        b += red[(w * BN + c) * 2 + 1];
+                    }
+                    float* dstp = p.bs_part + (int64_t)tile_m * 2 * p.Co;
+                    dstp[colc] = a;
+                    dstp[p.Co + colc] = b;
+                }
+            }
+        }
+    }
     // ---- fused BatchNorm statistics (bf16-storage training forward): per-column sum / sum of squares of this block's raw
     // conv outputs, from the fp32 ACCUMULATORS (before they are rounded to bf16), one row of the partial table
     // [tile_m][2 * Co] per M tile - no atomics, vd_bn_sum_partials finishes in fp64 in a fixed order (as k_conv_igemm)
@@ -611,13 +694,13 @@ inline bool halo_ok_b(const vd_conv_desc& d, int BM, int BN) {
     return BM + 2 * (d.Wi + 1) <= 9 * 64 && halo_lds_b(BM, BN, d.Wi) <= 160 * 1024;
 }
 
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false, bool HALO = false>
+template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false, bool HALO = false, bool BS = false>
 void launch_b2(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds_gen = 2 * (BM + BN) * ROW_B;
     const int lds = HALO ? (int)(halo_lds_b(BM, BN, d.Wi) > 8 * 32 * 36 * 4 ? halo_lds_b(BM, BN, d.Wi) : 8 * 32 * 36 * 4) : lds_gen;
     static bool attr_done = false;
-    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR, HALO>;
+    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR, HALO, BS>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   HALO ? 160 * 1024 : lds_gen);
@@ -633,6 +716,14 @@ void launch_b2(const vd_conv_desc& d, hipStream_t s) {
 
 template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false>
 void launch_b(const vd_conv_desc& d, hipStream_t s) {
+    if constexpr (!OUT_F32 && TM * TN <= 4) {
+        if (d.bs_part) {              // fused BatchNorm-backward reductions (the entry point keeps the other tiles out)
+            if constexpr (WM * WN == 8 && !PAIR) {
+                if (halo_ok_b(d, WM * TM * 32, WN * TN * 32)) return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, true, true>(d, s);
+            }
+            return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, false, true>(d, s);
+        }
+    }
     if constexpr (WM * WN == 8 && !PAIR && TM * TN <= 4) {
         if (halo_ok_b(d, WM * TM * 32, WN * TN * 32)) return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, true>(d, s);
     }
@@ -749,7 +840,17 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
     VD_REQUIRE(d->ldo >= d->Co && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31) && (int64_t)d->N * d->Hg * d->Wg < (1ll << 31),
                "vd_conv_igemm_bf16: bad sizes");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
-    VD_REQUIRE(!d->in_scale && !d->bs_part, "vd_conv_igemm_bf16: in-load transform / fused backward reductions are fp32-path features");
+    VD_REQUIRE(!d->in_scale, "vd_conv_igemm_bf16: the in-load transform is an fp32-path feature");
+    if (d->bs_part) {
+        const int t_ = (d->Ci == 32) ? 0 : ((d->tile <= 0 || d->tile > 13) ? (d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2)) : d->tile);
+        VD_REQUIRE(!out_f32 && t_ != 8 && t_ != 9, "vd_conv_igemm_bf16: fused backward reductions need a bf16 output and a tile other than 8 / 9");
+        VD_REQUIRE(d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd, "vd_conv_igemm_bf16: bs_* pointers missing");
+        VD_REQUIRE(d->ldo % 4 == 0 && d->Co % 4 == 0 && (uintptr_t)d->out % 16 == 0 && (uintptr_t)d->bs_z % 8 == 0 &&
+                   (((uintptr_t)d->bs_scale | (uintptr_t)d->bs_shift | (uintptr_t)d->bs_mean | (uintptr_t)d->bs_invstd) % 16 == 0) &&
+                   (!(d->flags & VD_EPI_RESIDUAL) || (d->ldr % 4 == 0 && (uintptr_t)d->residual % 8 == 0)) &&
+                   (!(d->flags & VD_EPI_AFFINE) || (((uintptr_t)d->scale | (uintptr_t)d->shift) % 16 == 0)),
+                   "vd_conv_igemm_bf16: fused backward reductions need the vector epilogue (aligned rows, Co % 4 == 0)");
+    }
     static const int probe = getenv("VD_IGEMM_PROBE") ? atoi(getenv("VD_IGEMM_PROBE")) : 0;
     vd_conv_desc dd = *d;
     dd.flags |= (probe & 7) << 8;

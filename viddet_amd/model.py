@@ -1935,11 +1935,12 @@ class YOLOV3(object):
         lib = L.load()
         s = L.stream_ptr()
         base = d.flags & ~L.MATH_NOHALO
-        key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.out_stride, bool(d.stats_part))
+        key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.out_stride, bool(d.stats_part),
+               bool(d.bs_part))
         if key not in _TUNE_CACHE:
             best, best_t = (0, L.MATH_NOHALO), None
             tiles = ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
-                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()))
+                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()))
             halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
             for c in tiles:
                 for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
@@ -2093,6 +2094,15 @@ class YOLOV3(object):
 
         bucket_hi, bucket_acc = [self.n_weight], [0]
         written, alias = set(self.head_names), {}
+        # BatchNorm backward reductions in the epilogue of the data gradient that completes dy of a BatchNorm output (the
+        # earliest forward consumer, processed last here), as in _build_train: the two-tensor reduction pass is skipped
+        producers = {m.dst: m for m in self.conv_nodes if m.bn}
+        consumers = {}
+        for m in self.nodes:
+            for t in ([m.src, m.residual] if isinstance(m, ConvNode) else [m.up, m.route]):
+                if t:
+                    consumers.setdefault(t, []).append(m)
+        fused_bwd = set()
         tgrad = {t: False for t in self.tensors}
         for m in self.nodes:
             if isinstance(m, ConvNode):
@@ -2170,9 +2180,10 @@ class YOLOV3(object):
                 slot = n_dz[0] % 2
                 n_dz[0] += 1
                 dz, ldd = dz_bufs[slot][:M * n.cout].view(-1, Ho, Wo, n.cout), n.cout
-                seg.add('vd_bn_bwd_reduce_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
-                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(), ws.data_ptr(), ws_bytes)
-                seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
+                if n.name not in fused_bwd:      # (fused: sums and gamma / beta gradients came with the table reduction)
+                    seg.add('vd_bn_bwd_reduce_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
+                            n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(), ws.data_ptr(), ws_bytes)
+                    seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
                 if side is not None and dz_free[slot] is not None:
                     seg.add_py(ev_wait(dz_free[slot], False))
                 seg.add('vd_bn_bwd_apply_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
@@ -2211,7 +2222,11 @@ class YOLOV3(object):
             dsrc, acc = grad_into(n.src, can_alias=True)
             res_src = alias.pop(n.src) if n.src in alias else dsrc
             kp = dz.shape[-1]                                   # K dimension of the data gradient (head: the padded pitch)
-            for plan in dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, 1, 0):
+            pm = producers.get(n.src)
+            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and consumers[n.src][0] is n) else None
+            bs_rows = 0
+            plans = dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, 1, 0)
+            for pi, plan in enumerate(plans):
                 assert plan['taps']
                 T = len(plan['taps'])
                 w32 = None
@@ -2229,11 +2244,23 @@ class YOLOV3(object):
                 if acc:
                     d.residual = res_src.data_ptr()
                 seg.hold(d, wbd)
+                if fuse_m is not None:
+                    d.bs_z = bufs['z:' + fuse_m.dst].data_ptr()
+                    d.bs_scale, d.bs_shift = fuse_m.b_scale.data_ptr(), fuse_m.b_shift.data_ptr()
+                    d.bs_mean, d.bs_invstd = fuse_m.b_mean.data_ptr(), fuse_m.b_invstd.data_ptr()
+                    d.bs_part, d.bs_slope = stats_ws.data_ptr() + bs_rows * 2 * fuse_m.cout * 4, LEAKY_SLOPE
                 self._tune_bf16_desc(d, 0)
+                if fuse_m is not None:
+                    bs_rows += lib.vd_conv_igemm_bf16_mtiles(C.byref(d))
+                    assert bs_rows * 2 * fuse_m.cout <= stats_ws.numel(), "stats workspace too small"
                 seg.add('vd_conv_igemm_bf16', C.byref(d), 0, meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
                     flops=2.0 * n.cin * n.cout * T * plan['Hg'] * plan['Wg'] * B,
                     bytes=fl(n, 'dgrad')['bytes'] / (n.stride * n.stride)))
+                if fuse_m is not None and pi == len(plans) - 1:
+                    seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), bs_rows, fuse_m.cout, fuse_m.sums2.data_ptr(),
+                            fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
+                    fused_bwd.add(fuse_m.name)
         if side is not None and last_side[0] is not None:
             seg.add_py(ev_wait(last_side[0], False))
         seg.hold(ws_w, side, stats_ws, ones, zeros)
