@@ -284,14 +284,16 @@ def _oracle_compare(net, P, c, x, gt, tg, out, loss_tol, whole_min, mean_min):
     assert 0.8 < np.sqrt(ng / nr) < 1.25
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (2, 20, 128, 4)])
-def test_training_step_in_bf16_storage_against_the_oracle(cfg):
+@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (2, 20, 128, 4), (2, 4, 64, 3, "fused")])
+def test_training_step_in_bf16_storage_against_the_oracle(cfg, monkeypatch):
     """One training step with bf16 activations and gradients against the fp64 oracle of the fp32 reference arithmetic.
     Tolerances are those of the bf16-PRODUCT arithmetic (tests/test_model_gpu.py::test_training_step_in_bf16_products:
     losses 5 %, whole-gradient cosine > 0.9): storing the tensors in bf16 adds one rounding per tensor to the rounding every
     conv operand already got there.  Every launch of the step must be a bf16-tensor kernel."""
     from tests.test_model_gpu import _mk_net, _targets
-    b, c, size, m = cfg
+    b, c, size, m = cfg[:4]
+    # "fused": the BatchNorm-backward reductions in the data-gradient epilogues (VD_FUSE_BWD_BF16=1; off by default)
+    monkeypatch.setenv("VD_FUSE_BWD_BF16", "1" if len(cfg) > 4 else "0")
     net, P = _mk_net(c, 6, obj_bias=-1.0)
     net.set_storage('bf16')
     rng = np.random.default_rng(6)
@@ -303,6 +305,7 @@ def test_training_step_in_bf16_storage_against_the_oracle(cfg):
     tp = net._last_train
     names = [fn_ for seg in tp['fwd'] + tp['bwd'] if hasattr(seg, 'recs') for (fn_, _, a) in seg.recs if fn_]
     assert names.count('vd_conv_igemm_bf16') > 140 and 'vd_conv_igemm' not in names and 'vd_bn_apply_leaky' not in names
+    assert (names.count('vd_bn_sum_param_grads') > 40) == (len(cfg) > 4)
     assert all(t.dtype == BF for k, t in tp['bufs'].items() if torch.is_tensor(t) and t.dim() == 4 and k not in net.head_names and k != 'in')
     _oracle_compare(net, P, c, x, gt, tg, out, 5e-2, 0.9, 0.7)
     # the optimiser step and a second forward on the moved weights (bf16 weight images are re-packed per step)

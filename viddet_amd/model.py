@@ -2223,7 +2223,11 @@ class YOLOV3(object):
             res_src = alias.pop(n.src) if n.src in alias else dsrc
             kp = dz.shape[-1]                                   # K dimension of the data gradient (head: the padded pitch)
             pm = producers.get(n.src)
-            fuse_m = pm if (self.fuse_bn_bwd and pm is not None and consumers[n.src][0] is n) else None
+            # (off by default in this mode, VD_FUSE_BWD_BF16=1: measured on one box, 416 / batch 64, 1992 frames/s with the
+            # stand-alone reduction passes against 1958 fused - the HBM-bound pass runs beside the side stream's MFMA-bound
+            # weight gradients, the fused epilogue lengthens the data gradients on the critical path)
+            fuse_m = pm if (__import__('os').environ.get('VD_FUSE_BWD_BF16', '0') == '1' and pm is not None and
+                            consumers[n.src][0] is n) else None
             bs_rows = 0
             plans = dgrad_plans(n.k, n.pad, n.stride, Hi, Wi, 1, 0)
             for pi, plan in enumerate(plans):
