@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, default=0, help="input side (default 416 train / 608 detect)")
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-detect", action="store_true", help="skip the detect (608x608, bf16) sub-line of the default training bench")
     ap.add_argument("--no-native", action="store_true", help="skip the VD_FP32_MATH=native sub-line of the training bench")
     ap.add_argument("--syncbn", default=None, choices=[None, "all", "reference"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16 = bf16 storage/MFMA inference (detect mode only)")
@@ -382,6 +383,25 @@ def main():
         finally:
             set_conv_math(None)
 
+    # ---- the metric's second half ("...; detect fps", BASELINE configs[1]: 608x608, bf16, detect_yolo3.py path) beside the
+    # training number of the default run: the same script as a child process (its own plans and calibration), its line
+    # embedded here - frames/s and the decode / NMS kernels' ms and GB/s at the calibrated pass fraction
+    detect = None
+    if train and rank == 0 and world == 1 and not force_dist and not a.no_detect and K == 1 and a.dtype == "f32" \
+            and a.batch == 0 and a.size == 0:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "detect", "--dtype", "bf16", "--steps", "20",
+                                "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+            dj = json.loads(r.stdout.strip().splitlines()[-1])
+            detect = {"metric": dj["metric"], "value": dj["value"], "unit": dj["unit"], "ms_per_step": dj["ms_per_step"],
+                      "dtype": dj["dtype"], "config": dj["config"]["workload"], "score_filter": dj["config"]["score_filter"],
+                      "roofline": {k: dj["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "launches") if k in dj["roofline"]},
+                      "kernels": {k: dj["kernels"][k] for k in ("decode_filter", "nms", "decode_plus_nms", "igemm_3x3s1_fwd")
+                                  if k in dj["kernels"]}}
+        except Exception as e:  # noqa: BLE001  (a diagnostic sub-line must never take the headline down)
+            detect = {"error": repr(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.mode, S, C)
@@ -422,6 +442,8 @@ def main():
                                      % os.environ.get("VD_FP32_MATH", "auto"))},
             "roofline": roof, "cpu_baseline": cpu, "kernels": extra, "phases": phases,
         }
+        if detect is not None:
+            out["detect"] = detect
         if gflop:
             out["model_tflops"] = round(fps * gflop / 1e3, 2)
         print(json.dumps(out))

@@ -132,6 +132,29 @@ def test_params_io_roundtrip(tmp_path):
         assert back[k].dtype == np.float32 and np.array_equal(back[k], arrs[k])
     raw = open(p, "rb").read()
     assert raw[:8] == (0x112).to_bytes(8, "little")
+    # the reader is strict: everything the layout does not allow fails loudly (no real MXNet file exists offline to
+    # validate the layout itself - SURVEY A.5 - so at least a mismatch can never load as garbage)
+    import struct
+
+    def broken(mut, msg):
+        b = bytearray(raw)
+        mut(b)
+        q = str(tmp_path / "bad.params")
+        open(q, "wb").write(bytes(b))
+        with pytest.raises(ValueError, match=msg):
+            load_params(q)
+
+    broken(lambda b: b.__setitem__(slice(0, 8), (0x113).to_bytes(8, "little")), "not an NDArray list")
+    broken(lambda b: b.__setitem__(slice(8, 16), (1).to_bytes(8, "little")), "reserved")
+    broken(lambda b: b.__setitem__(slice(24, 28), (0xdeadbeef).to_bytes(4, "little")), "unsupported NDArray magic")
+    broken(lambda b: b.__setitem__(slice(28, 32), struct.pack("<i", 1)), "sparse")
+    broken(lambda b: b.__setitem__(slice(32, 36), struct.pack("<I", 40)), "implausible rank")
+    broken(lambda b: b.__setitem__(slice(36, 44), struct.pack("<q", -3)), "negative dimension")
+    off_flag = 24 + 12 + 4 * 8 + 8                      # first array: magic, stype, ndim, 4 dims, dev_type, dev_id -> dtype flag
+    broken(lambda b: b.__setitem__(slice(off_flag, off_flag + 4), struct.pack("<i", 99)), "unknown dtype flag")
+    broken(lambda b: b.__delitem__(slice(len(b) - 7, len(b))), "implausible length|truncated")
+    broken(lambda b: b.extend(b"xx"), "trailing bytes")
+    broken(lambda b: b.__delitem__(slice(200, 1200)), "magic|past the end|truncated|names|length")
     with pytest.raises(ValueError):
         open(p, "wb").write(b"\0" * 64)
         load_params(p)

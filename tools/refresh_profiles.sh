@@ -17,20 +17,20 @@ python bench.py --dtype bf16 --size 608 --classes 285 --batch 32 --no-cpu-baseli
 echo "bf16 storage done"; cut -c1-160 $O/train_bf16storage_bench.json; cut -c1-160 $O/train_cfg4_bf16storage_bench.json; cut -c1-160 $O/train_cfg4_bf16products_bench.json
 # second start of the headline bench on the finished table: nothing is timed again (start-up time in the .time file)
 S0=$SECONDS
-python bench.py --no-cpu-baseline --no-native --steps 5 --warmup 2 > $O/train_second_start.json 2> $O/second.err
+python bench.py --no-cpu-baseline --no-native --no-detect --steps 5 --warmup 2 > $O/train_second_start.json 2> $O/second.err
 echo "$((SECONDS - S0)) s wall for a whole bench.py process (import, plan build from the persisted table, 2 + 5 steps, roofline replay)" > $O/second_start.time
 cat $O/second_start.time
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native > $O/prof_train.json 2> $O/prof_train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/prof_train.json 2> $O/prof_train.err
 echo "prof train done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_detect_bf16 -- python3 $R/bench.py --mode detect --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_detect_bf16.json 2> $O/prof_detect_bf16.err
 echo "prof detect done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16s -- python3 $R/bench.py --storage bf16 --size 608 --classes 285 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bf16s.json 2> $O/prof_bf16s.err
 python $R/tools/last_step_kernels.py $O/prof_bf16s $O/train_cfg4_bf16storage_last_step_kernels.json
 echo "prof bf16 storage done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-native > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-native > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/pmc_write.json 2> $O/pmc_write.err
 echo "pmc write done"
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last k_conv_igemm=163,k_conv_wgrad=74 | tail -3
@@ -38,7 +38,7 @@ python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last
 python tools/last_step_kernels.py $O/prof_train $O/train_last_step_kernels.json
 # the same step with the weight-gradient GEMMs on the main stream: every launch runs alone, so its rocprof duration is
 # comparable with bench.py's per-launch event timing (roofline.avg_launch_ms)
-(cd /tmp && VD_OVERLAP=0 rocprofv3 --kernel-trace --output-format csv -d $O/prof_train_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native > $O/prof_train_serial.json 2> $O/prof_train_serial.err)
+(cd /tmp && VD_OVERLAP=0 rocprofv3 --kernel-trace --output-format csv -d $O/prof_train_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/prof_train_serial.json 2> $O/prof_train_serial.err)
 python tools/last_step_kernels.py $O/prof_train_serial $O/train_last_step_kernels_serial.json
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O

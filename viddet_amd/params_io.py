@@ -41,43 +41,68 @@ def save_params(path, arrays):
 
 
 def load_params(path):
+    """Strict reader of the layout of SURVEY.md A.5 ([UPSTREAM-UNVERIFIED]: no real MXNet file exists offline to validate it
+    against).  Anything the layout does not allow - wrong magics, a non-zero reserved word, sparse storage, an unknown dtype
+    flag, implausible ranks / dimensions, a truncated or over-long file, a name count that differs from the array count -
+    raises ValueError naming the offset, never returns a partly decoded dict."""
     with open(path, "rb") as f:
         buf = f.read()
     off = 0
 
-    def rd(fmt):
+    def rd(fmt, what):
         nonlocal off
+        need = struct.calcsize(fmt)
+        if off + need > len(buf):
+            raise ValueError("%s: truncated at byte %d while reading %s" % (path, off, what))
         v = struct.unpack_from(fmt, buf, off)
-        off += struct.calcsize(fmt)
+        off += need
         return v
 
-    magic, _, n = rd("<QQQ")
+    magic, reserved, n = rd("<QQQ", "the list header")
     if magic != _LIST_MAGIC:
         raise ValueError("%s: not an NDArray list file (magic %#x)" % (path, magic))
+    if reserved != 0:
+        raise ValueError("%s: reserved header word is %#x, expected 0" % (path, reserved))
+    if n > (1 << 20):
+        raise ValueError("%s: implausible array count %d" % (path, n))
     arrs = []
-    for _ in range(n):
-        (m,) = rd("<I")
+    for i in range(n):
+        (m,) = rd("<I", "array %d's magic" % i)
         if m not in (_ND_MAGIC_V2, _ND_MAGIC_V3):
-            raise ValueError("%s: unsupported NDArray magic %#x" % (path, m))
-        (stype,) = rd("<i")
+            raise ValueError("%s: array %d at byte %d: unsupported NDArray magic %#x" % (path, i, off - 4, m))
+        (stype,) = rd("<i", "array %d's storage type" % i)
         if stype != 0:
-            raise ValueError("%s: sparse storage type %d not supported" % (path, stype))
-        (ndim,) = rd("<I")
-        shape = rd("<%dq" % ndim) if ndim else ()
-        _dev_type, _dev_id, flag = rd("<iii")
+            raise ValueError("%s: array %d: sparse storage type %d not supported" % (path, i, stype))
+        (ndim,) = rd("<I", "array %d's rank" % i)
+        if ndim > 8:
+            raise ValueError("%s: array %d: implausible rank %d" % (path, i, ndim))
+        shape = rd("<%dq" % ndim, "array %d's shape" % i) if ndim else ()
+        if any(d < 0 for d in shape):
+            raise ValueError("%s: array %d: negative dimension in %r" % (path, i, shape))
+        _dev_type, _dev_id, flag = rd("<iii", "array %d's context / dtype" % i)
+        if flag not in _DTYPES:
+            raise ValueError("%s: array %d: unknown dtype flag %d" % (path, i, flag))
         dt = np.dtype(_DTYPES[flag]).newbyteorder("<")
         cnt = int(np.prod(shape)) if ndim else 1
+        if off + cnt * dt.itemsize > len(buf):
+            raise ValueError("%s: array %d %r: data runs past the end of the file" % (path, i, shape))
         a = np.frombuffer(buf, dtype=dt, count=cnt, offset=off).reshape(shape)
         off += cnt * dt.itemsize
         arrs.append(a)
-    (nn,) = rd("<Q")
-    names = []
-    for _ in range(nn):
-        (ln,) = rd("<Q")
-        names.append(buf[off:off + ln].decode("utf-8"))
-        off += ln
+    (nn,) = rd("<Q", "the name count")
     if nn != n:
         raise ValueError("%s: %d arrays but %d names" % (path, n, nn))
+    names = []
+    for i in range(nn):
+        (ln,) = rd("<Q", "name %d's length" % i)
+        if ln > 4096 or off + ln > len(buf):
+            raise ValueError("%s: name %d: implausible length %d at byte %d" % (path, i, ln, off))
+        names.append(buf[off:off + ln].decode("utf-8"))
+        off += ln
+    if off != len(buf):
+        raise ValueError("%s: %d trailing bytes after the last name" % (path, len(buf) - off))
+    if len(set(names)) != len(names):
+        raise ValueError("%s: duplicate parameter names" % path)
     out = OrderedDict()
     for k, a in zip(names, arrs):
         for pre in ("arg:", "aux:"):
