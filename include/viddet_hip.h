@@ -384,6 +384,10 @@ int vd_bn_bwd_apply_bf16(const void* x, const void* dy, const float* scale, cons
 int vd_pack_weight_dgrad_bf16(const float* w, void* wp_bf16, int Co, int Co_pad, int Ci, int kd, int kh, int kw,
                               const int32_t* taps, int ntaps, int src_packed, void* stream);
 int vd_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* TemporalPooling (layers.py:161-205; type 0 = max, 1 = mean) over the K frames of a window on bf16 tensors: the bf16
+ * inference of the k > 1 networks.  vd_frame_slice / vd_temporal_cat are copies: they take bf16 tensors with the inner /
+ * channel counts halved (two bf16 = one 4-byte word). */
+int vd_temporal_pool_bf16(const void* x, void* y, int B, int K, int64_t inner, int type, void* stream);
 int vd_upsample2x_concat_bwd_bf16(const void* dout, void* dup, void* droute, int N, int Ho, int Wo, int Cu, int Cr, void* stream);
 int vd_stem_wgrad_bf16(const float* x_nchw, const void* dz, int ldd, float* dwp, int N, int H, int W, void* ws, int64_t ws_bytes,
                        void* stream);

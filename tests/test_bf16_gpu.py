@@ -120,3 +120,64 @@ def test_bf16_network_inference_close_to_fp32_oracle(c, b, size, obj_bias):
     again = net(dev(x))
     torch.cuda.synchronize()
     assert torch.equal(again[0], ids32) and torch.equal(again[2], bx32)
+
+
+def _heads_close(net, key_fp32, key_bf16, c, tol=3e-2):
+    """raw head outputs of the bf16 plan against the fp32 plan of the same shape: within `tol` of the head's max magnitude
+    (the bound test_bf16_network_inference_close_to_fp32_oracle holds the plain network to, against the oracle)."""
+    b32, b16 = net._programs[key_fp32], net._programs[key_bf16][1]
+    for hname in net.head_names:
+        ref = b32[hname][..., :3 * (5 + c)].float()
+        got = b16[hname][..., :3 * (5 + c)].float()
+        assert got.shape == ref.shape
+        rel = float((got - ref).abs().max()) / float(ref.abs().max())
+        print(hname, "bf16 vs fp32 tensors: max err / max|head| = %.4f" % rel)
+        assert rel < tol, (hname, rel)
+
+
+@pytest.mark.parametrize("cfg", [dict(jt="max", jp="early", bct="2"), dict(jt="mean", jp="late", bct="21"),
+                                 dict(jt="cat", jp="late", bct="3"), dict(jt="cat", jp="early", bct="2")])
+def test_bf16_inference_of_the_temporal_window_networks(cfg):
+    """k = 3 windows in bf16 (set_precision('bf16') used to be k = 1 only): TimeDistributed backbone, temporal pooling /
+    stacking, 3-D and 2+1-D neck convs - the fp32 heads of the bf16 plan against the fp32 plan (itself oracle-checked in
+    tests/test_temporal_gpu.py), and the same detections classes for the confident ones."""
+    from tests.test_temporal_gpu import _mk
+    c, b, size, K = 3, 2, 64, 3
+    net, P = _mk(cfg, c, 41)
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((b, K, 3, size, size)).astype(np.float32)
+    ids32, sc32, bx32 = [t.clone() for t in net(dev(x))]
+    net.set_precision('bf16')
+    ids, sc, bx = net(dev(x))
+    torch.cuda.synchronize()
+    assert tuple(ids.shape) == tuple(ids32.shape)
+    _heads_close(net, ('buf', b, size, size, False), ('infer_bf16', b, size, size), c)
+    net.set_precision('fp32')
+    again = net(dev(x))
+    assert torch.equal(again[0], ids32) and torch.equal(again[2], bx32)
+
+
+def test_bf16_inference_of_the_no_backbone_and_per_frame_output_networks():
+    from tests.test_noback_gpu import _mk_noback
+    from tests.test_temporal_out_gpu import _mk as _mk_tout, T_
+    # YOLOV3_noback: three cached fp32 feature maps in, converted to bf16 NHWC on the way
+    c, b, size = 4, 2, 64
+    P = ON.init_params(c, seed=13, obj_bias=-1.0)
+    net = _mk_noback(c, P)
+    rng = np.random.default_rng(13)
+    feats = [rng.standard_normal((b, ch, size // d, size // d)).astype(np.float32) for ch, d in ((256, 8), (512, 16), (1024, 32))]
+    r32 = [t.clone() for t in net(*[dev(f) for f in feats])]
+    net.set_precision('bf16')
+    r16 = net(*[dev(f) for f in feats])
+    torch.cuda.synchronize()
+    assert tuple(r16[0].shape) == tuple(r32[0].shape)
+    _heads_close(net, ('buf', b, size, size, False), ('infer_bf16', b, size, size), c)
+    # YOLOV3Temporal with per-frame outputs (t = 5): frame selections, valid-frame (3,1,1) convs, heads on every frame
+    net2, P2 = _mk_tout("21", 3, 51)
+    x = rng.standard_normal((1, T_, 3, size, size)).astype(np.float32)
+    a32 = [t.clone() for t in net2(dev(x))]
+    net2.set_precision('bf16')
+    a16 = net2(dev(x))
+    torch.cuda.synchronize()
+    assert tuple(a16[0].shape) == (1, T_, 100, 1) == tuple(a32[0].shape)
+    _heads_close(net2, ('buf', 1, size, size, False), ('infer_bf16', 1, size, size), 3)

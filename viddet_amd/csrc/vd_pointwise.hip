@@ -203,6 +203,25 @@ __global__ void k_tpool(const float* __restrict__ x, float* __restrict__ y, int3
     }
 }
 
+// bf16 tensors (bf16 inference of the k > 1 networks): 8 elements per thread, the max / mean in fp32
+__global__ void k_tpool_bf16(const __bf16* __restrict__ x, __bf16* __restrict__ y, int B, int K, int64_t inner8, int type) {
+    const int64_t total = (int64_t)B * inner8;
+    GRID_STRIDE(i, total) {
+        const int64_t b = i / inner8, r = i % inner8;
+        f32x8 v = vd_ld8(x, b * K * inner8 + r);
+        for (int k = 1; k < K; ++k) {
+            const f32x8 t = vd_ld8(x, (b * K + k) * inner8 + r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = type == 0 ? fmaxf(v[e], t[e]) : v[e] + t[e];
+        }
+        if (type != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] /= (float)K;
+        }
+        vd_st8(y, i, v);
+    }
+}
+
 __global__ void k_tpool_bwd(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx,
                             int B, int K, int64_t inner, int type) {
     const int64_t total = (int64_t)B * K * inner;
@@ -416,6 +435,14 @@ int vd_temporal_pool(const float* x, float* y, int32_t* argmax, int B, int K, in
     hipLaunchKernelGGL(k_tpool, dim3(sblocks((int64_t)B * inner)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B, K,
                        inner, type);
     VD_CHECK_LAUNCH("vd_temporal_pool");
+    return VD_OK;
+}
+
+int vd_temporal_pool_bf16(const void* x, void* y, int B, int K, int64_t inner, int type, void* stream) {
+    VD_REQUIRE(x && y && B > 0 && K > 0 && inner > 0 && inner % 8 == 0 && (type == 0 || type == 1), "vd_temporal_pool_bf16: bad args");
+    hipLaunchKernelGGL(k_tpool_bf16, dim3(sblocks((int64_t)B * (inner / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x,
+                       (__bf16*)y, B, K, inner / 8, type);
+    VD_CHECK_LAUNCH("vd_temporal_pool_bf16");
     return VD_OK;
 }
 

@@ -125,6 +125,7 @@ SIGNATURES = {
     "vd_bn_bwd_reduce_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "vd_bn_bwd_apply_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p]),
     "vd_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "vd_temporal_pool_bf16": (_i, [_p, _p, _i, _i, _i64, _i, _p]),
     "vd_pack_weight_dgrad_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _i, _p]),
     "vd_upsample2x_concat_bwd_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vd_stem_wgrad_bf16": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p]),

@@ -1216,55 +1216,90 @@ class YOLOV3(object):
         """'fp32' (reference precision) or 'bf16' (BASELINE configs[1]): bf16 storage + bf16 MFMA with fp32
         accumulation and fp32 epilogue for inference; the prediction heads stay fp32."""
         assert precision in ('fp32', 'bf16')
-        if precision == 'bf16' and self._k > 1:
-            raise NotImplementedError("bf16 inference is built for k=1")
         self.precision = precision
 
     def _build_infer_bf16(self, B, H, W):
+        """bf16 inference plan of every network variant: the plain net (BASELINE configs[1]), k > 1 windows (TimeDistributed
+        backbone = frames folded into the batch, temporal pooling / stacking, 3-D and 2+1-D neck convs through Kfr), the
+        no-backbone net (its three fp32 feature maps converted on the way in) and YOLOV3Temporal (frame selections, sums,
+        valid-frame convs, per-frame heads)."""
         dev = self.device
         lib = L.load()
+        BFT = torch.bfloat16
         # channel runs of 64 (one 128-byte K-step); a 32-channel map stays unpadded (two taps per K-step, vd_conv_bf16.hip)
         cp = lambda c: 32 if c == 32 else round_up(c, 64)
-        bufs = {'in': torch.empty(B, 3, H, W, device=dev)}
+        bufs = {}
         for name, (c, div, ld, fr) in self.tensors.items():
             if name == 'in':
-                continue
-            if name in self.head_names:
-                bufs[name] = torch.empty(B, H // div, W // div, ld, device=dev)
+                bufs['in'] = torch.empty(B * fr, 3, H, W, device=dev)
+            elif name in self.head_names:
+                bufs[name] = torch.empty(B * fr, H // div, W // div, ld, device=dev)
             else:
                 # zeros: padded channels are never written
-                bufs[name] = torch.zeros(B, H // div, W // div, cp(c), dtype=torch.bfloat16, device=dev)
+                bufs[name] = torch.zeros(B * fr, H // div, W // div, cp(c), dtype=BFT, device=dev)
         prog = Program()
         packs = []
-        s = L.stream_ptr()
+        if self.noback:
+            # the three cached feature maps arrive as fp32 NCHW: NHWC, then one conversion each
+            for nm, c_, d_ in ROUTE_TENSORS:
+                bufs['in:' + nm] = torch.empty(B, c_, H // d_, W // d_, device=dev)
+                bufs['f32:' + nm] = torch.empty(B, H // d_, W // d_, c_, device=dev)
+                assert cp(c_) == c_
+                prog.add('vd_nchw_to_nhwc', bufs['in:' + nm].data_ptr(), bufs['f32:' + nm].data_ptr(), B, c_, H // d_, W // d_)
+                n_el = bufs[nm].numel()
+                prog.add('vd_pack_weight_bf16', bufs['f32:' + nm].data_ptr(), bufs[nm].data_ptr(), 1, 1, n_el, n_el, 1)
         for n in self.nodes:
             if isinstance(n, UpcatNode):
                 o = bufs[n.dst]
                 # 16-byte-unit copy kernel: pass channel counts as if fp32 (bf16 count / 2)
-                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B,
+                prog.add('vd_upsample2x_concat', bufs[n.up].data_ptr(), bufs[n.route].data_ptr(), o.data_ptr(), B * n.fr,
                          o.shape[1], o.shape[2], cp(n.cu) // 2, cp(n.cr) // 2)
+                continue
+            if isinstance(n, PoolNode):
+                o, xs = bufs[n.dst], bufs[n.src]
+                if n.type == 2:          # stacking the K frames' channels: a copy (bf16 channel count / 2)
+                    assert xs.shape[3] % 8 == 0
+                    prog.add('vd_temporal_cat', xs.data_ptr(), o.data_ptr(), B, n.K, xs.shape[1] * xs.shape[2], xs.shape[3] // 2, 0)
+                else:
+                    prog.add('vd_temporal_pool_bf16', xs.data_ptr(), o.data_ptr(), B, n.K, o[0].numel(), n.type)
+                continue
+            if isinstance(n, SelNode):
+                xs, o = bufs[n.src], bufs[n.dst]
+                prog.add('vd_frame_slice', xs.data_ptr(), o.data_ptr(), B, n.K, n.k0, n.kc, xs[0].numel() // 2, 0)
+                continue
+            if isinstance(n, AddNode):
+                a_, b_, o = bufs[n.a], bufs[n.b], bufs[n.dst]
+                prog.add('vd_add_bf16', a_.data_ptr(), b_.data_ptr(), o.data_ptr(), o.numel())
                 continue
             if n.stem:
                 # fp32 master weights and BN fold on the fp32 VALU, bf16 output (vd_stem.hip)
                 self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True,
                                bf16=True)
                 continue
+            tvalid = getattr(n, 'tvalid', False)
             ci_p = cp(n.cin)
             co_p = n.co_pad if n.head else cp(n.cout)
-            wb = torch.empty(co_p * n.T * ci_p, dtype=torch.bfloat16, device=dev)
+            wb = torch.empty(co_p * n.T * ci_p, dtype=BFT, device=dev)
             packs.append((n, wb, co_p, ci_p))
             d = ConvDesc()
             x = bufs[n.src]
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
-            d.in_, d.wp, d.out = x.data_ptr(), wb.data_ptr(), bufs[n.dst].data_ptr()
-            d.N, d.Hi, d.Wi, d.Ci = B, Hi, Wi, ci_p
+            out = bufs[n.dst]
+            if tvalid:
+                # (3,1,1) conv without temporal padding = frames [1, K-1) of the 'same'-padded one: all frames go through
+                # the conv and its (per-channel, batch-independent) BN-fold epilogue, the valid ones are sliced out
+                if ('zf:' + n.dst) not in bufs:
+                    bufs['zf:' + n.dst] = torch.zeros(B * n.fr, Ho, Wo, co_p, dtype=BFT, device=dev)
+                out = bufs['zf:' + n.dst]
+            d.in_, d.wp, d.out = x.data_ptr(), wb.data_ptr(), out.data_ptr()
+            d.N, d.Hi, d.Wi, d.Ci = B * n.fr, Hi, Wi, ci_p
             d.Hg, d.Wg, d.in_stride = Ho, Wo, n.stride
             ops._set_taps(d, n.taps())
-            d.Kfr = 1
+            d.Kfr = n.fr if n.kd > 1 else 1
             d.Ho, d.Wo, d.Co = Ho, Wo, co_p
             d.out_stride, d.out_oy, d.out_ox = 1, 0, 0
-            d.ldo = d.ldr = co_p
+            d.ldo = d.ldr = out.shape[-1]
             if n.head:
                 d.flags, d.shift = EPI_AFFINE, n.bias.data_ptr()
             else:
@@ -1280,23 +1315,26 @@ class YOLOV3(object):
             d.slope = LEAKY_SLOPE
             prog.hold(d, wb)
             prog.add('vd_conv_igemm_bf16', C.byref(d), 1 if n.head else 0, meta=self._flops(n, B, H, W, 'fwd'))
+            if tvalid:
+                prog.add('vd_frame_slice', out.data_ptr(), bufs[n.dst].data_ptr(), B, n.fr, 1, n.fr - 2, out[0].numel() // 2, 0)
         grids = self._grid(H, W)
+        Bh = B * self._head_frames           # images the decode / NMS see (B*t with per-frame predictions)
         hd = ops.make_head_desc([bufs[h] for h in self.head_names], grids, round_up(3 * (5 + self.num_class), 32),
-                                STRIDES[::-1], ANCHORS[::-1], B, self.num_class)
+                                STRIDES[::-1], ANCHORS[::-1], Bh, self.num_class)
         P = 3 * sum(g * g for g in grids)
         cap = self.num_class * P          # no candidate cap (see _build_infer)
-        o = dict(cand_score=torch.empty(B, cap, device=dev), cand_row=torch.empty(B, cap, dtype=torch.int32, device=dev),
-                 counts=torch.zeros(B, dtype=torch.int32, device=dev), ids=torch.empty(B, self.post_nms, 1, device=dev),
-                 scores=torch.empty(B, self.post_nms, 1, device=dev), bboxes=torch.empty(B, self.post_nms, 4, device=dev),
-                 rows=torch.empty(B, self.post_nms, dtype=torch.int32, device=dev),
-                 overflow=torch.zeros(B, dtype=torch.int32, device=dev))
+        o = dict(cand_score=torch.empty(Bh, cap, device=dev), cand_row=torch.empty(Bh, cap, dtype=torch.int32, device=dev),
+                 counts=torch.zeros(Bh, dtype=torch.int32, device=dev), ids=torch.empty(Bh, self.post_nms, 1, device=dev),
+                 scores=torch.empty(Bh, self.post_nms, 1, device=dev), bboxes=torch.empty(Bh, self.post_nms, 4, device=dev),
+                 rows=torch.empty(Bh, self.post_nms, dtype=torch.int32, device=dev),
+                 overflow=torch.zeros(Bh, dtype=torch.int32, device=dev))
         prog.hold(hd, o)
         prog.add('vd_yolo_decode_filter', C.byref(hd), 0.01, o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
                  o['counts'].data_ptr())
         prog.add('vd_nms_topk', C.byref(hd), o['cand_score'].data_ptr(), o['cand_row'].data_ptr(), cap,
                  o['counts'].data_ptr(), float(self.nms_thresh), int(self.nms_topk), int(self.post_nms),
                  o['ids'].data_ptr(), o['scores'].data_ptr(), o['bboxes'].data_ptr(), o['rows'].data_ptr(),
-                 o['overflow'].data_ptr(), 4 * B)
+                 o['overflow'].data_ptr(), 4 * Bh)
         return prog, bufs, o, packs
 
     def _refresh_bf16(self, packs):
@@ -1322,7 +1360,7 @@ class YOLOV3(object):
                 continue
             d, of32 = args[0]._obj, args[1]
             base = d.flags & ~L.MATH_NOHALO
-            key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32)
+            key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.Kfr)
             if key not in _TUNE_CACHE:
                 best, best_t = (2, 0), None
                 verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
@@ -1364,8 +1402,6 @@ class YOLOV3(object):
     def _forward_infer(self, x):
         B, H, W = self._in_shape(x)
         assert 0 < self.nms_thresh < 1, "nms_thresh outside (0,1) (NMS disabled) is not implemented"
-        if self.precision == 'bf16' and (self.noback or self.temporal_out):
-            raise NotImplementedError("bf16 inference of the no-backbone / per-frame-output variants is not built")
         if self.precision == 'bf16':
             key = ('infer_bf16', B, H, W)
             if key not in self._programs:
