@@ -129,8 +129,9 @@ class TuneCache(dict):
         import hashlib
         import os
         here = os.path.dirname(os.path.abspath(__file__))
-        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_common.h")] + \
-               [os.path.join(os.path.dirname(here), "include", "viddet_hip.h")]
+        # the conv kernels' sources (the public header is not part of it: declarations of other entry points change there
+        # without touching a tile; descriptor layouts are guarded by the ABI revision)
+        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_common.h")]
         h = hashlib.sha256()
         if all(os.path.exists(f) for f in srcs):
             for f in srcs:
