@@ -512,3 +512,49 @@ def test_configs4_shape_combined_classes_bf16_products():
     finally:
         M.set_conv_math(None)
         M._TUNE_CACHE.clear()
+
+
+def test_plan_eviction_when_the_next_shape_does_not_fit_beside_the_others(monkeypatch):
+    """Random-shape training keeps one plan (buffers + programs) per input shape; when the next shape's plan does not fit
+    beside the cached ones they are dropped and the build is retried (`_build_or_evict`).  The retry must run OUTSIDE the
+    except block: inside it the failed build's half-allocated buffers are still referenced by the live traceback and
+    cannot be returned to the driver (ADVICE, round 2).  Forced here with a per-process memory cap between 'both plans' and
+    'the larger plan alone'; the step after eviction must equal a fresh network's, bit for bit (pinned kernels)."""
+    monkeypatch.setenv("VD_AUTOTUNE", "0")
+    c = 4
+    rng = np.random.default_rng(77)
+    xa = rng.standard_normal((8, 3, 256, 256)).astype(np.float32)
+    xb = rng.standard_normal((8, 3, 320, 320)).astype(np.float32)
+    ta, tb = _targets(rng, 8, c, 256, 3), _targets(rng, 8, c, 320, 3)
+
+    def step(net, x, t):
+        out = net(dev(x), dev(t[0]), *[dev(v) for v in t[1]])
+        net.backward()
+        torch.cuda.synchronize()
+        return [o.clone() for o in out], net.grads.clone()
+
+    def reserved():
+        torch.cuda.synchronize()
+        return torch.cuda.memory_reserved()
+
+    total = torch.cuda.get_device_properties(0).total_memory
+    try:
+        import gc
+        fresh, _ = _mk_net(c, 15, obj_bias=-1.0)
+        ref = step(fresh, xb, tb)
+        del fresh
+        gc.collect(); torch.cuda.empty_cache()
+        net, P = _mk_net(c, 15, obj_bias=-1.0)
+        base = reserved()
+        step(net, xa, ta)
+        m_a = reserved() - base
+        # room for plan A plus HALF of what plan B needs beside it (B's buffers are (320/256)^2 = 1.56 x A's)
+        cap = reserved() + int(0.8 * m_a)
+        torch.cuda.set_per_process_memory_fraction(min(1.0, cap / total))
+        got = step(net, xb, tb)                       # does not fit beside A: A is evicted, B is built again and runs
+        assert ('train', 8, 320, 320) in net._programs and ('train', 8, 256, 256) not in net._programs
+        assert all(torch.equal(a, b) for a, b in zip(got[0], ref[0])) and torch.equal(got[1], ref[1])
+        step(net, xa, ta)                             # and back: B is evicted in turn
+        assert ('train', 8, 256, 256) in net._programs
+    finally:
+        torch.cuda.set_per_process_memory_fraction(1.0)
