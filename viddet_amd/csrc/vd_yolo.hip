@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, flo
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int npred = 5 + h.C, A = 3 * npred;
-    float* row = smem + wave * (A + 4);
+    float* row = smem + wave * (((A + 3) & ~3) + 4);       // 16-byte aligned rows
     const int R0 = h.g[0] * h.g[0], R1 = h.g[1] * h.g[1], R2 = h.g[2] * h.g[2];
     const int R = R0 + R1 + R2;
     if (threadIdx.x == 0) {
@@ -68,14 +68,48 @@ __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, flo
         lfill = 1 << 30;                      // base of the first reservation that did not fit (none yet)
     }
     __syncthreads();
-    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+    // Row staging: one 16-byte load per lane covers a whole 256-float head row, and the NEXT row of this wave is requested
+    // before the current one is decoded (round 2's form - 4 B per lane, one row in flight per wave - ran at 1.55 TB/s on
+    // 248 MB).  vec: rows start 16-byte aligned and hold a whole number of float4s (every plan of the network).
+    constexpr int NV = 4;                    // float4s per lane: rows of up to 1024 floats (C <= 336)
+    const int RW = (A + 3) & ~3;
+    const bool vec = (h.ldh % 4 == 0) && RW <= NV * 256 &&
+                     ((((uintptr_t)h.head[0] | (uintptr_t)h.head[1] | (uintptr_t)h.head[2]) & 15) == 0);
+    auto row_src = [&](int r) -> const float* {
+        int s, pix;
+        if (r < R0) { s = 0; pix = r; }
+        else if (r < R0 + R1) { s = 1; pix = r - R0; }
+        else { s = 2; pix = r - R0 - R1; }
+        return h.head[s] + ((int64_t)b * h.g[s] * h.g[s] + pix) * h.ldh;
+    };
+    f32x4 nx[NV];
+    auto fetch = [&](int r) {
+        const float* src = row_src(r);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int e = 4 * lane + 256 * v;
+            nx[v] = e < RW ? *reinterpret_cast<const f32x4*>(src + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int rstep = gridDim.x * 4;
+    if (vec && (int)(blockIdx.x * 4 + wave) < R) fetch(blockIdx.x * 4 + wave);
+    for (int r = blockIdx.x * 4 + wave; r < R; r += rstep) {
         int s, pix, rowbase;
         if (r < R0) { s = 0; pix = r; rowbase = 0; }
         else if (r < R0 + R1) { s = 1; pix = r - R0; rowbase = h.C * 3 * R0; }
         else { s = 2; pix = r - R0 - R1; rowbase = h.C * 3 * (R0 + R1); }
         const int g = h.g[s];
-        const float* src = h.head[s] + ((int64_t)b * g * g + pix) * h.ldh;
-        for (int e = lane; e < A; e += 64) row[e] = src[e];
+        if (vec) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int e = 4 * lane + 256 * v;
+                if (e < RW) *reinterpret_cast<f32x4*>(row + e) = nx[v];
+            }
+            if (r + rstep < R) fetch(r + rstep);
+        } else {
+            const float* src = row_src(r);
+            for (int e = lane; e < A; e += 64) row[e] = src[e];
+        }
         WAVE_SYNC();
         const float o0 = vd_sigmoid(row[4]), o1 = vd_sigmoid(row[npred + 4]), o2 = vd_sigmoid(row[2 * npred + 4]);
         // sigmoid(cls) < 1  =>  score < obj : an anchor whose objectness fails the threshold has no
@@ -529,7 +563,7 @@ int vd_yolo_decode_filter(const vd_head_desc* h, float valid_thresh, float* cand
         return VD_ELAUNCH;
     }
     const int A = 3 * (5 + h->C);
-    const int lds = 4 * (A + 4) * (int)sizeof(float);
+    const int lds = 4 * (((A + 3) & ~3) + 4) * (int)sizeof(float);
     VD_REQUIRE(lds <= 64 * 1024, "vd_yolo_decode_filter: too many classes for the LDS row stage");
     const int nb = loss_blocks(h);
     hipLaunchKernelGGL(k_decode_filter, dim3(nb, h->B), dim3(256), lds, s, *h, valid_thresh, cand_score, cand_row, cap,
