@@ -69,6 +69,8 @@ def parse_flags(argv=None):
     A("--offset", type=int, default=0)
     A("--hier_level", type=int, default=10)
     A("--synthetic_samples", type=int, default=32)
+    A("--precision", default="fp32", choices=["fp32", "bf16"],
+      help="(no reference counterpart) bf16: bf16 storage + bf16 MFMA inference, fp32 heads (net.set_precision, BASELINE configs[1])")
     A("--synthetic_classes", type=int, default=None, help="classes per dataset of the synthetic combined set (default: the datasets' own counts)")
     A("--random_init", type=_bool, nargs="?", const=True, default=False,
       help="skip load_parameters (no checkpoint available offline)")
@@ -175,6 +177,7 @@ def main(argv=None):
         net.initialize(init="he", obj_bias=-2.0)
     else:
         net.load_parameters(FLAGS.model_path)
+    net.set_precision(FLAGS.precision)
     save_dir = os.path.join(FLAGS.save_dir, FLAGS.save_prefix, "pred")
     boxes = detect(net, dataset, loader, FLAGS.max_do)
     if world > 1:

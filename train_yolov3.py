@@ -106,6 +106,9 @@ def parse_flags(argv=None):
     A("--hier", type=_list, default=["1"] * 5)
     A("--max_epoch_time", type=int, default=-1)
     A("--synthetic_samples", type=int, default=128, help="size of the synthetic stand-in dataset")
+    A("--storage", default="fp32", choices=["fp32", "bf16"],
+      help="(no reference counterpart) bf16: training activations and gradients in bf16, fp32 statistics / losses / master "
+           "weights - net.set_storage('bf16'), BASELINE configs[4]; single-frame yolo3_darknet53 only")
     return ap.parse_args(argv)
 
 
@@ -210,6 +213,8 @@ def get_net(classes, rank_world):
                           k=k, k_join_type=FLAGS.k_join_type, k_join_pos=FLAGS.k_join_pos,
                           block_conv_type=FLAGS.block_conv_type, temporal=FLAGS.temp, t_out=FLAGS.mult_out)   # :348-360
     net.initialize(init="he", seed=FLAGS.seed)
+    if FLAGS.storage == "bf16":
+        net.set_storage("bf16")                       # raises for the window / per-frame-output variants
     start_epoch = FLAGS.start_epoch
     if FLAGS.resume.strip():
         start_epoch = resume(net, FLAGS.resume, FLAGS.start_epoch)
