@@ -156,11 +156,11 @@ def test_train_script_default_path(tmp_path, monkeypatch):
     assert "[Epoch 1][Batch 0/1]" in log
     assert all(bool(torch.isfinite(p.data()).all()) for p in net3.collect_params().values())
     # --storage bf16 (BASELINE configs[4]'s mode through the entry point) and detect_yolo3.py --precision bf16 on its checkpoint
-    net4 = T.main(["--batch_size", "4", "--data_shape", "64", "--epochs", "0", "--synthetic_samples", "4", "--save_prefix", "0000",
+    net4 = T.main(["--batch_size", "4", "--data_shape", "64", "--epochs", "1", "--synthetic_samples", "4", "--save_prefix", "0000",
                    "--storage", "bf16", "--no_random_shape", "--val_interval", "1", "--num_workers", "0", "--log_interval", "1"])
     assert net4._last_train.get('storage') == 'bf16' and all(bool(torch.isfinite(p.data()).all()) for p in net4.collect_params().values())
     import detect_yolo3 as D
-    ck4 = str(pre / "yolo3_darknet53_voc_0000.params")
+    ck4 = str(pre / "yolo3_darknet53_voc_0001.params")
     out4 = D.main(["--model_path", ck4, "--dataset", "voc", "--batch_size", "4", "--data_shape", "64", "--synthetic_samples", "4",
                    "--save_prefix", "b16", "--precision", "bf16"])
     assert out4 is not None

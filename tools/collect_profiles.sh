@@ -27,5 +27,6 @@ python tools/summarize_rocprof.py $O/prof_train $P/${T}_train_b64_416_kernel_sum
 python tools/summarize_rocprof.py $O/prof_detect_bf16 $P/${T}_detect_b32_608_bf16_kernel_summary.md
 cp $O/pmc_traffic.json $P/${T}_train_b64_416_pmc_traffic.json
 cp $O/train_last_step_kernels.json $P/${T}_train_last_step_kernels.json
+[ -f $O/detect_bf16_last_step_kernels.json ] && cp $O/detect_bf16_last_step_kernels.json $P/${T}_detect_b32_608_bf16_last_step_kernels.json
 cp $O/train_last_step_kernels_serial.json $P/${T}_train_last_step_kernels_serial.json
 ls -la $P/${T}_*

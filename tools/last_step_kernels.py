@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-family launch count / average duration over the LAST training step of a rocprofv3 --kernel-trace run (the step
 between the last two optimiser launches), i.e. without the plan-time autotuner's trial launches that the --stats summary
-of the whole process includes.  usage: last_step_kernels.py <dir with *_kernel_trace.csv> <out.json>"""
+of the whole process includes.  usage: last_step_kernels.py <dir with *_kernel_trace.csv> <out.json> [--detect]"""
 import csv
 import glob
 import json
@@ -21,9 +21,15 @@ def main():
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    sgd = [i for i, r in enumerate(rows) if "k_sgd" in r[2]]
-    # two k_sgd launches per step (weights; gamma/beta/bias): the step is everything after the previous step's second one
-    a, b = sgd[-3] + 1, sgd[-1] + 1
+    if len(sys.argv) > 3 and sys.argv[3] == "--detect":
+        # inference: a step ends with its k_nms launch; the last step runs at the calibrated objectness bias (the sweep that
+        # finds it - all-pass biases included - comes first and must not be averaged in)
+        nms = [i for i, r in enumerate(rows) if "k_nms" in r[2]]
+        a, b = nms[-2] + 1, nms[-1] + 1
+    else:
+        sgd = [i for i, r in enumerate(rows) if "k_sgd" in r[2]]
+        # two k_sgd launches per step (weights; gamma/beta/bias): the step is everything after the previous step's second one
+        a, b = sgd[-3] + 1, sgd[-1] + 1
     step = rows[a:b]
     agg = defaultdict(lambda: [0, 0])
     for s, e, n in step:

@@ -24,6 +24,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/prof_train.json 2> $O/prof_train.err
 echo "prof train done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_detect_bf16 -- python3 $R/bench.py --mode detect --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_detect_bf16.json 2> $O/prof_detect_bf16.err
+python $R/tools/last_step_kernels.py $O/prof_detect_bf16 $O/detect_bf16_last_step_kernels.json --detect
 echo "prof detect done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16s -- python3 $R/bench.py --storage bf16 --size 608 --classes 285 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bf16s.json 2> $O/prof_bf16s.err
 python $R/tools/last_step_kernels.py $O/prof_bf16s $O/train_cfg4_bf16storage_last_step_kernels.json
