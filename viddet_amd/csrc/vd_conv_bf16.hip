@@ -738,8 +738,13 @@ void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
         if (tile == 13) return launch_b<2, 2, 2, 1, OUT_F32, true>(d, s);
         return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
     }
-    if (tile <= 0 || tile > 13) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
+    if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
     switch (tile) {
+        // 14, 15: small four-wave tiles (37 / 28 KB of LDS: four or five workgroups per CU) for the short-K 1x1 layers, which
+        // are HBM-bound and ran at half the HBM rate on the large tiles: one workgroup's load latency and output stores
+        // hide behind its neighbours'
+        case 14: return launch_b<2, 2, 1, 1, OUT_F32>(d, s);  //  64 x 64, 4 waves of 32x32
+        case 15: return launch_b<4, 1, 1, 1, OUT_F32>(d, s);  // 128 x 32, 4 waves of 32x32
         case 10: return launch_b<4, 2, 2, 1, OUT_F32>(d, s);  // 256 x 64, 8 waves of 64x32
         case 11: return launch_b<4, 1, 2, 2, OUT_F32>(d, s);  // 256 x 64, 4 waves of 64x64
         case 12: return launch_b<4, 1, 2, 1, OUT_F32>(d, s);  // 256 x 32, 4 waves of 64x32
@@ -818,10 +823,10 @@ extern "C" {
 static int bf16_tile_bm(const vd_conv_desc& d) {
     int tile = d.tile;
     if (d.Ci == 32) return tile == 13 ? 128 : 256;
-    if (tile <= 0 || tile > 13) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
+    if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
     switch (tile) {
         case 10: case 11: case 12: case 8: case 9: case 6: return 256;
-        case 13: case 7: case 1: case 2: case 3: return 128;
+        case 13: case 7: case 1: case 2: case 3: case 15: return 128;
         default: return 64;
     }
 }
@@ -842,7 +847,7 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
     VD_REQUIRE(!d->in_scale, "vd_conv_igemm_bf16: the in-load transform is an fp32-path feature");
     if (d->bs_part) {
-        const int t_ = (d->Ci == 32) ? 0 : ((d->tile <= 0 || d->tile > 13) ? (d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2)) : d->tile);
+        const int t_ = (d->Ci == 32) ? 0 : ((d->tile <= 0 || d->tile > 15) ? (d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2)) : d->tile);
         VD_REQUIRE(!out_f32 && t_ != 8 && t_ != 9, "vd_conv_igemm_bf16: fused backward reductions need a bf16 output and a tile other than 8 / 9");
         VD_REQUIRE(d->bs_z && d->bs_scale && d->bs_shift && d->bs_mean && d->bs_invstd, "vd_conv_igemm_bf16: bs_* pointers missing");
         VD_REQUIRE(d->ldo % 4 == 0 && d->Co % 4 == 0 && (uintptr_t)d->out % 16 == 0 && (uintptr_t)d->bs_z % 8 == 0 &&
