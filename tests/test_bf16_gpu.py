@@ -28,6 +28,9 @@ _BF16_CASES = [(t, sh) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9)
 _BF16_CASES += [(t, sh) for t in (10, 11, 13) for sh in [(2, 64, 17, 15, 64, 3, 1, 1), (2, 128, 9, 9, 64, 1, 1, 0),
                                                       (2, 32, 19, 21, 64, 3, 1, 1), (2, 32, 18, 20, 64, 3, 2, 1),
                                                       (1, 32, 9, 9, 64, 1, 1, 0), (3, 32, 40, 24, 40, 3, 1, 1)]]
+# 14 / 15: the small four-wave tiles of the short-K 1x1 layers (also on the two-tap layout of 32-channel inputs)
+_BF16_CASES += [(14, (2, 128, 9, 9, 64, 1, 1, 0)), (14, (2, 64, 13, 11, 128, 1, 1, 0)), (14, (3, 32, 12, 10, 64, 1, 1, 0)),
+                (14, (2, 64, 17, 15, 64, 3, 1, 1)), (15, (2, 64, 21, 19, 32, 1, 1, 0)), (15, (2, 128, 12, 12, 24, 3, 1, 1))]
 _BF16_CASES += [(12, (2, 64, 21, 19, 32, 1, 1, 0)), (12, (2, 64, 12, 12, 24, 3, 1, 1)), (0, (2, 64, 21, 19, 32, 1, 1, 0)),
                 (0, (2, 64, 17, 15, 64, 3, 1, 1)), (0, (2, 64, 17, 15, 256, 3, 1, 1))]
 

@@ -736,6 +736,7 @@ void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
     if (d.Ci == 32) {                                          // two taps per K-step; these layers have Co = 64
         if (tile == 11) return launch_b<4, 1, 2, 2, OUT_F32, true>(d, s);
         if (tile == 13) return launch_b<2, 2, 2, 1, OUT_F32, true>(d, s);
+        if (tile == 14) return launch_b<2, 2, 1, 1, OUT_F32, true>(d, s);     // 64 x 64, four waves (short-K 1x1: see tile 14 below)
         return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
     }
     if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
@@ -822,7 +823,7 @@ extern "C" {
 // rows of the GEMM one workgroup covers, per tile variant (dispatch_b below)
 static int bf16_tile_bm(const vd_conv_desc& d) {
     int tile = d.tile;
-    if (d.Ci == 32) return tile == 13 ? 128 : 256;
+    if (d.Ci == 32) return tile == 14 ? 64 : (tile == 13 ? 128 : 256);
     if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
     switch (tile) {
         case 10: case 11: case 12: case 8: case 9: case 6: return 256;

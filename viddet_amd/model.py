@@ -1365,8 +1365,10 @@ class YOLOV3(object):
             if key not in _TUNE_CACHE:
                 best, best_t = (2, 0), None
                 verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
-                tiles = ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
-                         else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()))
+                one = d.T == 1           # 14 / 15: small four-wave tiles for the HBM-bound 1x1 layers
+                tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+                         else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
+                         else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()) + ((14,) if one else ()))
                 # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
                 # does not apply) is timed against the generic one
                 halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0
@@ -1976,8 +1978,11 @@ class YOLOV3(object):
                bool(d.bs_part))
         if key not in _TUNE_CACHE:
             best, best_t = (0, L.MATH_NOHALO), None
-            tiles = ((10, 11, 13) if d.Ci == 32 else (12, 10, 11, 13) if d.Co <= 32 else (10, 11, 13, 2, 3, 4, 5) if d.Co <= 64
-                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()))
+            # 14 / 15: the small four-wave tiles (64x64 / 128x32, four or five workgroups per CU) for the HBM-bound 1x1 layers
+            one = d.T == 1
+            tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+                     else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
+                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()) + ((14,) if one else ()))
             halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
             for c in tiles:
                 for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
