@@ -334,7 +334,15 @@ def test_stem_direct_conv_forward_wgrad_stats(shape):
     ops.stem_conv(xd, wp, ob, scale=dev(sc), shift=dev(sh), leaky=True)
     torch.cuda.synchronize()
     assert maxdiff(dev_nhwc_to_nchw(out), refa) < TOL
-    assert maxdiff(dev_nhwc_to_nchw(ob.float(), 32), refa) < 2.0 ** -8 * max(1.0, float(np.abs(refa).max()))
+    # bf16 output = the matrix-pipe form (two bf16 MFMAs per 32 pixels on the frame values and weights rounded to bf16, fp32
+    # accumulation): exact against the oracle on the ROUNDED operands up to fp32 summation and one rounding of the output,
+    # and within bf16 operand accuracy of the fp32 result
+    rb = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+    ub = R.conv2d(rb(x), rb(wt), 1, 1) * sc[None, :, None, None] + sh[None, :, None, None]
+    refb = np.where(ub > 0, ub, 0.1 * ub)
+    gotb = dev_nhwc_to_nchw(ob.float(), 32)
+    assert maxdiff(gotb, refb) < 2e-4 + 2.0 ** -8 * float(np.abs(refb).max())
+    assert maxdiff(gotb, refa) < 3e-2 * max(1.0, float(np.abs(refa).max()))
     assert float(ob[..., 32:].float().abs().max()) == 0.0
     # weight gradient
     dy = rng.standard_normal((n, 32, h, w))

@@ -15,6 +15,7 @@
 //               straight from global memory - lane (co, pixel parity) reads dz coalesced, lane (k, pixel parity)
 //               gathers its frame value - no LDS, no im2col; per-block partial tiles + a fixed-order reduction.
 #include "vd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,12 +26,73 @@ constexpr int SK = 27;          // 3 * 3 * 3 real taps x channels; packed weight
 constexpr int SPX = 256;        // pixels per workgroup (one per lane)
 
 // w: fwd-packed [32][32] with k = (ky*3 + kx)*3 + c  (vd_pack_weight_fwd of the OIHW stem weight; k >= 27 are zero)
-template <bool OUT_BF16>
+// MF (bf16 outputs: bf16 inference and bf16-storage training, where every conv operand is bf16-rounded anyway): the 864 FMAs
+// per pixel go to the matrix pipe instead - per 32 pixels two v_mfma_f32_32x32x16_bf16 (K = 27 padded to 32) on the frame
+// values and weights rounded to bf16 in registers, fp32 accumulation; the gathers, the LDS tile, the statistics and the
+// stores are the VALU form's.  (The VALU form was compute-bound at 0.43-0.47 ms for 11 M pixels; fp32 tensors keep it:
+// it is exact fp32.)
+template <bool OUT_BF16, bool MF = false>
 __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   void* __restrict__ out, int ldo, int N, int H, int W,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   float slope, int flags, float* __restrict__ stats_part) {
     __shared__ float tile[SPX][SC + 1];           // +1: the transposing reads walk a column
+    if constexpr (MF) {
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int64_t HW = (int64_t)H * W;
+        const int64_t P = (int64_t)N * HW;
+        const int hh = lane >> 5;                 // operand k-half: k = 8*hh .. +7 (first MFMA), 16 + 8*hh .. (second)
+        // B operand: lane (co = lane & 31, hh) holds w[co][k] for its 2 x 8 k values (k >= 27 are zero in the packed rows)
+        bf16x8_t b0, b1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            b0[e] = (__bf16)w[(lane & 31) * 32 + 8 * hh + e];
+            b1[e] = (__bf16)w[(lane & 31) * 32 + 16 + 8 * hh + e];
+        }
+#pragma unroll
+        for (int gsel = 0; gsel < 2; ++gsel) {    // a wave owns 64 of the workgroup's 256 pixels: two 32-pixel MFMA row blocks
+            const int prow = wave * 64 + gsel * 32 + (lane & 31);
+            const int64_t pix = (int64_t)blockIdx.x * SPX + prow;
+            bf16x8_t a0, a1;
+            {
+                const bool pin = pix < P;
+                const int64_t pp = pin ? pix : 0;
+                const int n = (int)(pp / HW);
+                const int r = (int)(pp - (int64_t)n * HW);
+                const int y = r / W, xx = r - y * W;
+                const float* xn = x + (int64_t)n * 3 * HW;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = (e < 8 ? 8 * hh : 16 + 8 * hh) + (e & 7);          // this lane's e-th k
+                    const int tap = k / 3, c = k - 3 * tap;
+                    const int iy = y + tap / 3 - 1, ix = xx + tap % 3 - 1;
+                    const bool ok = pin && k < SK && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    const float t = xn[ok ? (int64_t)c * HW + (int64_t)iy * W + ix : 0];
+                    v[e] = ok ? t : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] = (__bf16)v[e]; a1[e] = (__bf16)v[8 + e]; }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[r2] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            // C/D map: acc[r] = C[row (r & 3) + 8 (r >> 2) + 4 hh][col lane & 31]; epilogue per column, then into the tile
+            const int co = lane & 31;
+            const float sc = (flags & VD_EPI_AFFINE) ? scale[co] : 1.f, sh = (flags & VD_EPI_AFFINE) ? shift[co] : 0.f;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                float t = acc[r2];
+                if (flags & VD_EPI_AFFINE) t = t * sc + sh;
+                if (flags & VD_EPI_LEAKY) t = t > 0.f ? t : t * slope;
+                tile[wave * 64 + gsel * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * hh][co] = t;
+            }
+        }
+        __syncthreads();
+    } else {
     // weights transposed to [k][co] in LDS: for one k the 32 output-channel weights are 8 broadcast ds_read_b128
     // (every lane the same address).  Kept in SGPRs they spilled: 864 values against 100 scalar registers.
     __shared__ __attribute__((aligned(16))) float wT[SK][SC];
@@ -84,6 +146,9 @@ __global__ __launch_bounds__(SPX) void k_stem_fwd(const float* __restrict__ x, c
         tile[tid][c] = v;
     }
     __syncthreads();
+    }   // !MF
+    const int tid = threadIdx.x;
+    const int64_t P = (int64_t)N * H * W;
     // fused BatchNorm statistics of the raw outputs (training; flags == 0, so the tile holds them): column sums out of
     // the LDS tile - 8 row segments x 32 columns per pass, then 64 lanes fold the 8 partials (rows past the last pixel
     // hold zeros).  One table row per workgroup.  (Per-column wave shuffles cost 384 cross-lane ops per wave.)
@@ -218,7 +283,11 @@ int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N
     VD_REQUIRE(!stats_part || flags == 0, "vd_stem_conv: fused statistics need the raw output (they come from the fp32 values, bf16 output or not)");
     VD_REQUIRE((int64_t)N * H * W < (1ll << 31), "vd_stem_conv: pixel count overflows int32");
     const int nb = vd_stem_conv_blocks(N, H, W);
-    if (out_bf16)
+    static const int use_mf = getenv("VD_STEM_MFMA") ? atoi(getenv("VD_STEM_MFMA")) : 1;      // developer A/B switch
+    if (out_bf16 && use_mf)
+        hipLaunchKernelGGL((k_stem_fwd<true, true>), dim3(nb), dim3(SPX), 0, (hipStream_t)stream, x_nchw, wp, out, ldo, N, H, W,
+                           scale, shift, slope, flags, stats_part);
+    else if (out_bf16)
         hipLaunchKernelGGL(k_stem_fwd<true>, dim3(nb), dim3(SPX), 0, (hipStream_t)stream, x_nchw, wp, out, ldo, N, H, W,
                            scale, shift, slope, flags, stats_part);
     else
