@@ -63,6 +63,11 @@ extern "C" {
  * products are the one-term bf16 MFMA of VD_MATH_BF16 on operands that are ALREADY bf16, the weight gradient stays fp32.
  * The forward / data-gradient convs of that mode are vd_conv_igemm_bf16. */
 #define VD_STORE_BF16    256
+/* VD_WGRAD_HALO (vd_wgrad_desc.flags, with VD_MATH_F16X2 or VD_STORE_BF16): where the launch is a 3x3 / stride-1 / 'same'
+ * weight gradient with Co >= 128, a workgroup owns BM output channels x (9 taps x 32 input channels) and stages the
+ * activation rows ONCE per pixel in a sliding LDS ring that the nine taps read at shifted rows (vd_wgrad_halo.hip), instead
+ * of gathering the activation tile once per tap.  Same arithmetic, slabs and reduction; other geometries ignore the flag. */
+#define VD_WGRAD_HALO    512
 #define VD_AMAX_SLOTS    32
 #define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
 #define VD_AMAX_FLOATS   (VD_AMAX_SLOTS * VD_AMAX_STRIDE)   /* floats per tensor */

@@ -19,6 +19,7 @@
 //   C/D map: acc[r] -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31  => a store instruction writes two
 //   128-B row segments (channel-contiguous NHWC).
 #include "vd_common.h"
+#include "vd_wgrad_halo.h"
 #include <stdlib.h>
 
 namespace {
@@ -1934,7 +1935,7 @@ int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
 
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d) {
     if (!d) return 0;
-    const int s = wgrad_pick_splits(*d);
+    const int s = vd_wgrad_halo_ok(*d) ? vd_wgrad_halo_splits(*d) : wgrad_pick_splits(*d);
     return (s > 1) ? (int64_t)s * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
 }
 
@@ -1950,13 +1951,24 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
                "vd_conv_wgrad: VD_MATH_F16X2 needs amax_in and amax_dout (and no in-load transform)");
     VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31) && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31),
                "vd_conv_wgrad: pixel count overflows int32");
-    const int splits = wgrad_pick_splits(*d);
+    const bool halo = vd_wgrad_halo_ok(*d);           // VD_WGRAD_HALO and a geometry the halo-ring kernel serves
+    const int splits = halo ? vd_wgrad_halo_splits(*d) : wgrad_pick_splits(*d);
     const int64_t need = (splits > 1) ? (int64_t)splits * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && !ws)) {
         vd_set_error("vd_conv_wgrad: workspace %lld < %lld", (long long)ws_bytes, (long long)need);
         return VD_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (halo) {
+        vd_wgrad_halo_launch(*d, (splits > 1) ? (float*)ws : d->dwp, splits, s);
+        VD_CHECK_LAUNCH("vd_conv_wgrad/halo");
+        if (splits > 1) {
+            const int64_t n4 = (int64_t)d->Co * d->T * d->Ci / 4;
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)vd_cdiv(n4, 64)), dim3(64), 0, s, (const float*)ws, d->dwp, n4, splits);
+            VD_CHECK_LAUNCH("vd_conv_wgrad/reduce");
+        }
+        return VD_OK;
+    }
     const int64_t P = (int64_t)d->N * d->Hg * d->Wg;
     const int bp = (d->flags & VD_STORE_BF16) ? WG_BP_BF : WG_BP;
     int64_t pps = vd_cdiv(vd_cdiv(P, splits), bp) * bp;

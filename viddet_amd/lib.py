@@ -18,6 +18,7 @@ MATH_BF16 = 32         # products on bf16-rounded operands (one MFMA term), fp32
 MATH_F16X2 = 64        # two-way fp16 operand split with per-tensor power-of-two scales (three MFMA terms, fp32-accurate)
 MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-staged one (A/B timing)
 STORE_BF16 = 256       # vd_wgrad_desc.flags: `in` / `dout` are bf16 tensors (bf16-storage training)
+WGRAD_HALO = 512       # vd_wgrad_desc.flags: halo-ring kernel for 3x3 / stride-1 weight gradients (vd_wgrad_halo.hip)
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 

@@ -131,7 +131,7 @@ class TuneCache(dict):
         here = os.path.dirname(os.path.abspath(__file__))
         # the conv kernels' sources (the public header is not part of it: declarations of other entry points change there
         # without touching a tile; descriptor layouts are guarded by the ABI revision)
-        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_common.h")]
+        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_wgrad_halo.hip", "vd_common.h")]
         h = hashlib.sha256()
         if all(os.path.exists(f) for f in srcs):
             for f in srcs:
@@ -345,6 +345,45 @@ def autotune_desc(d, reps=3):
     _TUNE_CACHE[key] = best
 
 
+def _wgrad_halo_applies(d):
+    """the geometry test of vd_wgrad_halo_ok (vd_wgrad_halo.hip); the library ignores VD_WGRAD_HALO elsewhere, this only
+    keeps launches that cannot use it out of the timing loop"""
+    return d.T == 9 and d.in_stride == 1 and d.Kfr == 1 and d.Hg == d.Hi and d.Wg == d.Wi and d.Co >= 128 and \
+        d.Ci % 32 == 0 and 5 <= d.Wi <= 208 and not d.in_scale
+
+
+def autotune_wgrad_bf16(d, ws_ptr, ws_bytes, reps=2):
+    """bf16-stored operands: generic kernel vs the halo ring, timed in place (the flag is ignored where it does not apply)"""
+    import os
+    d.flags = L.STORE_BF16 | L.MATH_BF16
+    if not _wgrad_halo_applies(d) or os.environ.get("VD_WGRAD_HALO", "1") != "1":
+        return
+    if os.environ.get("VD_AUTOTUNE", "1") == "0":
+        d.flags |= L.WGRAD_HALO
+        return
+    key = ('wgrad_bf16', d.N, d.Hi, d.Wi, d.Ci, d.Co)
+    if key not in _TUNE_CACHE:
+        lib = L.load()
+        s = L.stream_ptr()
+        best, best_t = 0, None
+        for fl in (0, L.WGRAD_HALO):
+            d.flags = L.STORE_BF16 | L.MATH_BF16 | fl
+            L.check(lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s), 'vd_conv_wgrad/tune')
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if os.environ.get("VD_TUNE_VERBOSE") == "1":
+                print("wgrad bf16 tune %s halo %d: %.4f ms" % (key[1:], fl, t / reps), flush=True)
+            if best_t is None or t < best_t:
+                best, best_t = fl, t
+        _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
+    d.flags = L.STORE_BF16 | L.MATH_BF16 | _TUNE_CACHE[key]
+
+
 def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     """Product arithmetic of one weight-gradient launch record (fp32 MFMA vs the split forms), timed in place."""
     import os
@@ -356,15 +395,17 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
         d.flags = L.MATH_BF16
         return
     f16 = L.MATH_F16X2 if (d.amax_in and d.amax_dout and not d.in_scale) else L.MATH_SPLIT
+    # the halo-ring kernel (vd_wgrad_halo.hip) where the library takes it: 3x3 / stride 1 / Co >= 128, fp16 split
+    halo = L.WGRAD_HALO if (f16 == L.MATH_F16X2 and _wgrad_halo_applies(d) and os.environ.get("VD_WGRAD_HALO", "1") == "1") else 0
     if math in ("split", "split2") or os.environ.get("VD_AUTOTUNE", "1") == "0":
-        d.flags = f16 if math in ("split2", "auto") else L.MATH_SPLIT
+        d.flags = (f16 | halo) if math in ("split2", "auto") else L.MATH_SPLIT
         return
-    key = ('wgrad', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.Kfr, bool(d.in_scale), f16)
+    key = ('wgrad', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, d.Kfr, bool(d.in_scale), f16 | halo)
     if key not in _TUNE_CACHE:
         lib = L.load()
         s = L.stream_ptr()
         best, best_t = 0, None
-        for fl in dict.fromkeys((0, L.MATH_SPLIT, f16)):
+        for fl in dict.fromkeys((0, L.MATH_SPLIT, f16, f16 | halo)):
             d.flags = fl
             L.check(lib.vd_conv_wgrad(C.byref(d), ws_ptr, ws_bytes, s), 'vd_conv_wgrad/tune')
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -2043,9 +2084,10 @@ class YOLOV3(object):
             else:
                 wd_ = WgradDesc()
                 wd_.N, wd_.Hi, wd_.Wi, wd_.Ci, wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = B, Hi, Wi, n.cin, Ho, Wo, n.co_pad, n.co_pad
-                wd_.in_stride, wd_.Kfr, wd_.flags = n.stride, 1, L.STORE_BF16 | L.MATH_BF16
                 ops._set_taps(wd_, n.taps())
-                ws_bytes = max(ws_bytes, int(lib.vd_conv_wgrad_ws_bytes(C.byref(wd_))))
+                for fl_ in (0, L.WGRAD_HALO):          # the halo-ring kernel picks its own split count
+                    wd_.in_stride, wd_.Kfr, wd_.flags = n.stride, 1, L.STORE_BF16 | L.MATH_BF16 | fl_
+                    ws_bytes = max(ws_bytes, int(lib.vd_conv_wgrad_ws_bytes(C.byref(wd_))))
             ws_bytes = max(ws_bytes, ops.bn_stats_ws_bytes(B * Ho * Wo, hb(n.co_pad)))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         smax = 16
@@ -2240,6 +2282,7 @@ class YOLOV3(object):
                     wd_.Hg, wd_.Wg, wd_.Co, wd_.ldd = Ho, Wo, n.co_pad, ldd
                     wd_.in_stride, wd_.Kfr, wd_.splits, wd_.flags = n.stride, 1, 0, L.STORE_BF16 | L.MATH_BF16
                     ops._set_taps(wd_, n.taps())
+                    autotune_wgrad_bf16(wd_, ws.data_ptr(), ws_bytes)
                     seg.hold(wd_)
                     wargs = ('vd_conv_wgrad', C.byref(wd_))
                 if side is not None:

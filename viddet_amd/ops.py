@@ -171,8 +171,8 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = kfr, splits
     d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
-    if split in ('f16x2', 'f16x2nh'):
-        d.flags = MATH_F16X2
+    if split in ('f16x2', 'f16x2nh', 'f16x2h'):
+        d.flags = MATH_F16X2 | (L.WGRAD_HALO if split == 'f16x2h' else 0)     # 'f16x2h': the halo-ring kernel where it applies
         amax_in = amax(x) if amax_in is None else amax_in
         amax_dout = amax(dout) if amax_dout is None else amax_dout
         d.amax_in, d.amax_dout = ptr(amax_in), ptr(amax_dout)
@@ -180,7 +180,7 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
         d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
     if x.dtype == torch.bfloat16:               # bf16-storage training: both operands bf16, the gradient fp32
         assert dout.dtype == torch.bfloat16 and dwp.dtype == torch.float32
-        d.flags = L.STORE_BF16 | MATH_BF16
+        d.flags = L.STORE_BF16 | MATH_BF16 | (L.WGRAD_HALO if split == 'halo' else 0)
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
     if need > ws.numel() * ws.element_size():
@@ -195,8 +195,11 @@ def wgrad_ws_bytes(N, Hi, Wi, Ci, Ho, Wo, Co, k, stride, pad, kd=1, pad_d=0):
     _set_taps(d, fwd_taps(k, pad, kd, pad_d))
     d.Kfr, d.splits = 1, 0
     need = 0
-    for fl in (0, MATH_SPLIT):          # the product arithmetics pick different split counts (every split form: the same)
+    # the product arithmetics pick different split counts (every split form: the same); the halo-ring kernel its own.  The
+    # library only looks at shapes and flags here, so a non-null placeholder stands for the max-abs pointers of MATH_F16X2
+    for fl in (0, MATH_SPLIT, MATH_F16X2 | L.WGRAD_HALO, L.STORE_BF16 | L.WGRAD_HALO):
         d.flags = fl
+        d.amax_in = d.amax_dout = 1 if fl & MATH_F16X2 else None
         need = max(need, _lib().vd_conv_wgrad_ws_bytes(C.byref(d)))
     return need
 
