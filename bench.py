@@ -351,6 +351,21 @@ def main():
         for k, v in agg.items():
             if k != "vd_conv_igemm" and v[1] > 0:
                 extra[k] = {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 3), "launches": v[2]}
+        if "vd_conv_wgrad" in extra:
+            # the weight gradients by kernel and geometry: k_conv_wgrad_halo (3x3 stride 1, Co >= 128) against the generic
+            # kernel's 3x3 stride-1 leftovers, the 1x1 layers (HBM-bound: two activation tensors per 2 Ci Co FLOPs a pixel)
+            # and the stride-2 layers
+            cls = {}
+            for r in detail:
+                if r["fn"] != "vd_conv_wgrad":
+                    continue
+                key = "halo_3x3s1" if r.get("wgrad_halo") else ("generic_3x3s1" if (r["k"] == 3 and r["stride"] == 1) else
+                                                                 "generic_1x1" if r["k"] == 1 else "generic_3x3s2")
+                c = cls.setdefault(key, [0.0, 0.0, 0, 0.0])
+                c[0] += r["flops"]; c[1] += r["ms"]; c[2] += 1; c[3] += r.get("bytes", 0.0)
+            extra["vd_conv_wgrad"]["by_kernel"] = {
+                k_: {"launches": c[2], "ms": round(c[1], 3), "tflops": round(c[0] / (c[1] * 1e-3) / 1e12, 1),
+                     "algorithmic_gb_s": round(c[3] / (c[1] * 1e-3) / 1e9, 0)} for k_, c in cls.items()}
         extra["conv_ms_per_step"] = round(sum(v[1] for k, v in agg.items() if k.startswith("vd_")), 3)
         if a.detail:
             with open(a.detail, "w") as f:

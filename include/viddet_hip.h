@@ -191,6 +191,9 @@ typedef struct {
 
 int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d);
 int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stream);
+/* 1 when vd_conv_wgrad(d) would run the halo-ring kernel (VD_WGRAD_HALO set and the geometry / arithmetic is one it
+ * serves), else 0: for host autotuners (no point timing the flag where it is ignored) and tests. */
+int vd_conv_wgrad_uses_halo(const vd_wgrad_desc* d);
 
 /* Direct stem convolution (3x3, 3 -> 32 channels, stride 1, pad 1; three_darknet.py:163-164) straight from the NCHW
  * fp32 frame batch (transforms.py:239-245): no im2col round trip.  wp is the fwd-packed stem weight [32][32]

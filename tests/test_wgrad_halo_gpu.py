@@ -20,16 +20,33 @@ TOL = 2e-4
 BF = torch.bfloat16
 
 CASES = [  # n, ci, h, w, co, splits
-    (4, 128, 26, 26, 256, 0),      # 8-wave tile (256 output channels), ring of 128 rows
-    (3, 64, 13, 13, 128, 0),       # 4-wave tile, a step (32 positions) spans more than two image rows
-    (2, 32, 15, 17, 160, 3),       # one channel chunk, ragged second co tile, odd split count, H != W
-    (2, 96, 9, 11, 288, 1),        # single split: the kernel writes dwp itself (no slabs), ragged 256-row tile
+    (4, 128, 26, 26, 256, 0),      # 128 co x two chunks (the tile of every layer with Ci % 64 == 0), ring of 128 rows
+    (3, 64, 13, 13, 128, 0),       # a step (32 positions) spans more than two image rows
+    (2, 32, 15, 17, 288, 3),       # one chunk: the 256-row tile (ragged second co tile), odd split count, H != W
+    (2, 96, 9, 11, 288, 1),        # single split: the kernel writes dwp itself (no slabs); Ci = 96 takes the 256-row tile
     (1, 64, 52, 52, 128, 5),       # ring of 256 rows
-    (1, 32, 104, 104, 128, 7),     # ring of 512 rows, several wraps per range
-    (2, 32, 6, 5, 128, 2),         # the smallest map the kernel takes (W = 5)
+    (1, 64, 104, 104, 160, 7),     # two chunks x 512 rows do not fit LDS: the 320-row ring that wraps by compare; ragged co
+    (2, 64, 6, 5, 128, 2),         # the smallest map the kernel takes (W = 5)
     (5, 64, 19, 19, 256, 0),       # a 608-family size: the pad column makes rows of 20 positions
-    (1, 32, 40, 208, 128, 0),      # the widest map (ring 512 rows = 64 + 2 * 224)
+    (1, 32, 40, 208, 256, 0),      # the widest map (ring 512 rows = 64 + 2 * 224), 256-row tile
 ]
+
+
+def _uses_halo(x, dout, co, mode):
+    """does the library take the halo-ring kernel for this launch? (a test that silently ran the generic one proves nothing)"""
+    import ctypes as C
+    from viddet_amd import lib as L, ops
+    d = L.WgradDesc()
+    N, Hi, Wi, Ci = x.shape
+    d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.Co, d.ldd = N, Hi, Wi, Ci, Hi, Wi, co, dout.shape[-1]
+    d.in_stride, d.Kfr = 1, 1
+    ops._set_taps(d, ops.fwd_taps(3, 1))
+    if x.dtype == torch.bfloat16:
+        d.flags = L.STORE_BF16 | L.MATH_BF16 | L.WGRAD_HALO
+    else:
+        d.flags = L.MATH_F16X2 | L.WGRAD_HALO
+        d.amax_in = d.amax_dout = 1          # only tested for NULL
+    return bool(L.load().vd_conv_wgrad_uses_halo(C.byref(d)))
 
 
 def _ref_wgrad(x, dy, co, ci):
@@ -46,6 +63,7 @@ def test_halo_wgrad_matches_oracle(case):
     dw_ref = _ref_wgrad(x, dy, co, ci)
     ws = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
     xd, dyd = nchw_to_dev_nhwc(x), nchw_to_dev_nhwc(dy)
+    assert _uses_halo(xd, dyd, co, "f16x2h")
     err = {}
     for mode in ("f16x2h", "f16x2"):
         dwp = torch.full((co, 9 * ci), 5.0, device="cuda")
@@ -71,6 +89,7 @@ def test_halo_wgrad_padded_dout_pitch_and_operand_scales():
     dyd[..., :co] = nchw_to_dev_nhwc(dy)
     ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
     dwp = torch.empty(co, 9 * ci, device="cuda")
+    assert _uses_halo(nchw_to_dev_nhwc(x), dyd, co, "f16x2h")
     ops.conv_wgrad(nchw_to_dev_nhwc(x), dyd, dwp, ws, k=3, stride=1, pad=1, Co=co, split="f16x2h")
     dw = torch.empty(co, ci, 3, 3, device="cuda")
     ops.unpack_weight(dwp, dw)
@@ -92,7 +111,7 @@ def test_halo_wgrad_is_deterministic_and_ignored_where_it_does_not_apply():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     # stride 2, 1x1 and Co < 128: the flag is ignored - bit for bit the generic kernel's result
-    for (ci2, co2, k, s, p) in ((64, 128, 3, 2, 1), (128, 256, 1, 1, 0), (64, 64, 3, 1, 1)):
+    for (ci2, co2, k, s, p) in ((64, 128, 3, 2, 1), (128, 256, 1, 1, 0), (64, 64, 3, 1, 1), (32, 128, 3, 1, 1)):     # (last: one chunk would need the 256-row tile)
         rng, x, _ = _mk(2, ci2, 14, 14, co2, k, 3)
         ho = (14 + 2 * p - k) // s + 1
         xd, dyd = nchw_to_dev_nhwc(x), nchw_to_dev_nhwc(rng.standard_normal((2, co2, ho, ho)))
@@ -111,8 +130,8 @@ def _nhwc_b(a):
     return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1)).astype(np.float32)).to(BF).cuda()
 
 
-@pytest.mark.parametrize("case", [(4, 128, 26, 26, 256, 0), (3, 64, 13, 13, 128, 0), (2, 32, 15, 17, 160, 3), (1, 64, 52, 52, 128, 5),
-                                  (2, 96, 9, 11, 288, 1)])
+@pytest.mark.parametrize("case", [(4, 128, 26, 26, 256, 0), (3, 64, 13, 13, 128, 0), (2, 32, 15, 17, 288, 3), (1, 64, 52, 52, 128, 5),
+                                  (2, 96, 9, 11, 288, 1), (1, 64, 104, 104, 160, 7), (1, 64, 38, 208, 128, 0)])
 def test_halo_wgrad_from_bf16_operands(case):
     from viddet_amd import ops
     n, ci, h, w, co, splits = case
@@ -122,6 +141,7 @@ def test_halo_wgrad_from_bf16_operands(case):
     dw_ref = _ref_wgrad(x, dz, co, ci)
     ws = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
     dwp = torch.full((co, 9 * ci), 3.0, device="cuda")
+    assert _uses_halo(_nhwc_b(x), _nhwc_b(dz), co, "halo")
     ops.conv_wgrad(_nhwc_b(x), _nhwc_b(dz), dwp, ws, k=3, stride=1, pad=1, Co=co, splits=splits, split="halo")
     dw = torch.empty(co, ci, 3, 3, device="cuda")
     ops.unpack_weight(dwp, dw)

@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = ["k_conv_igemm_bf16", "k_conv_igemm", "k_conv_wgrad", "k_bn_partial", "k_bn_apply_leaky", "k_bn_bwd_apply",
+FAMILIES = ["k_conv_igemm_bf16", "k_conv_igemm", "k_conv_wgrad_halo", "k_conv_wgrad", "k_bn_partial", "k_bn_apply_leaky", "k_bn_bwd_apply",
             "k_reduce_slabs", "k_bn_sum_partials", "k_stem_im2col", "k_sgd", "k_yolo_loss", "k_upcat"]
 
 

@@ -34,9 +34,12 @@ echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/pmc_write.json 2> $O/pmc_write.err
 echo "pmc write done"
 cd $R
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last k_conv_igemm=163,k_conv_wgrad=74 | tail -3
 # keep only the small summaries
 python tools/last_step_kernels.py $O/prof_train $O/train_last_step_kernels.json
+# launches per step of the three conv kernels, from the trace of the same command (the autotuner decides how many weight
+# gradients take the halo-ring kernel)
+LAST=$(python -c "import json,sys; k=json.load(open('$O/train_last_step_kernels.json'))['kernels']; print(','.join('%s=%d' % (n, k[n]['launches']) for n in ('k_conv_igemm','k_conv_wgrad','k_conv_wgrad_halo') if n in k))")
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json --last $LAST | tail -4
 # the same step with the weight-gradient GEMMs on the main stream: every launch runs alone, so its rocprof duration is
 # comparable with bench.py's per-launch event timing (roofline.avg_launch_ms)
 (cd /tmp && VD_OVERLAP=0 rocprofv3 --kernel-trace --output-format csv -d $O/prof_train_serial -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-native --no-detect > $O/prof_train_serial.json 2> $O/prof_train_serial.err)

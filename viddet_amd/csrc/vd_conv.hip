@@ -1939,6 +1939,8 @@ int64_t vd_conv_wgrad_ws_bytes(const vd_wgrad_desc* d) {
     return (s > 1) ? (int64_t)s * d->Co * d->T * d->Ci * (int64_t)sizeof(float) : 0;
 }
 
+int vd_conv_wgrad_uses_halo(const vd_wgrad_desc* d) { return (d && vd_wgrad_halo_ok(*d)) ? 1 : 0; }
+
 int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stream) {
     VD_REQUIRE(d && d->in && d->dout && d->dwp, "vd_conv_wgrad: null pointer");
     VD_REQUIRE(d->Ci > 0 && d->Ci % 4 == 0 && d->Co % 4 == 0, "vd_conv_wgrad: Ci=%d Co=%d must be multiples of 4", d->Ci, d->Co);

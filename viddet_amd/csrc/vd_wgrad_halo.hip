@@ -85,9 +85,11 @@ struct WhCursor {      // a position of the padded space: column, row within the
     int x, y, pr;      // real-pixel index of (n, y, 0)
 };
 
-template <int BM, bool BF>
+// P2: the ring has a power-of-two row count (wrap = one and); otherwise it has exactly the 64 + 2 hloa rows the window
+// needs and wraps by compare - the form that lets the two-chunk tile of a 104-wide map fit LDS (320 rows instead of 512).
+template <int BM, bool BF, bool P2>
 __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc p, float* __restrict__ dst, const int64_t q_per_split,
-                                                            const int ring_log2, const int hloa, const int64_t zd_in,
+                                                            const int ring_rows, const int hloa, const int64_t zd_in,
                                                             const int64_t zd_do) {
     constexpr int NT = 512;
     constexpr int NPL = BF ? 1 : 2;
@@ -108,9 +110,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As3 = reinterpret_cast<char*>(smem);           // [2][NPL][32][BM] fp16
     char* Xr = As3 + 2 * NPL * APL;                      // [NCH][NPL][RING + 32][64 B]
-    const int RING = 1 << ring_log2;
+    const int RING = ring_rows;                          // a multiple of 32
     const int XPL = (RING + WH_MIR) * 64;                // bytes of one ring plane
-    const int RBMASK = RING * 64 - 1;
+    const int RB = RING * 64;                            // bytes of the ring proper
+    auto wrapB = [&](int a) -> int {                     // byte offset in (-RB, 2 RB) -> [0, RB)
+        if (P2) return a & (RB - 1);
+        a += a < 0 ? RB : 0;
+        a -= a >= RB ? RB : 0;
+        return a;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     };
     auto compute = [&](int buf) {
         const char* a3 = As3 + buf * NPL * APL + a_off;
-        auto at = [&](int t) { return (xb + tapB[t]) & RBMASK; };      // tap t's ring address: one add, one and
+        auto at = [&](int t) { return wrapB(xb + tapB[t]); };         // tap t's ring address: one add, one and (P2)
         v4i fa[NPL], fb[2][NPL];
         readA(fa, a3, 0);
         readB(fb[0], at(0), 0);
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
             }
             __builtin_amdgcn_s_setprio(0);
         }
-        xb = (xb + WH_BP * 64) & RBMASK;
+        xb = wrapB(xb + WH_BP * 64);
     };
 
     // ---- prologue: ring rows [0, 32 + 2 hloa) = positions q_begin - hloa ..; dout tile 0 -> stage 0
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     lstoreA(0, ra[0]);
     __syncthreads();
     gloadA(ra[1]);
-    int xrow = (WH_BP + 2 * hloa + xj) & (RING - 1);     // ring row of the lane's position in block 0
+    int xrow = wrapB((WH_BP + 2 * hloa + xj) * 64) >> 6; // ring row of the lane's position in block 0
 
     // One step: request tile s+2 and block s, multiply tile s, store tile s+1 and block s (read from step s+1 on).
     // Requests past the range read the zero page and the stage / ring rows they land in are never read, so the loop has no
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
         compute(u & 1);
         if (!late) lstoreA((u + 1) & 1, ra[(u + 1) & 1]);
         if (xact) xstore_row(xv, xrow);
-        xrow = (xrow + WH_BP) & (RING - 1);
+        xrow = wrapB((xrow + WH_BP) * 64) >> 6;
         __syncthreads();
     };
     for (int ks = 0; ks < nks; ks += 2) {
@@ -397,31 +405,42 @@ const void* zero_page_wh() {
 }
 
 int wh_hloa(const vd_wgrad_desc& d) { return ((d.Wi + 2 + 31) / 32) * 32; }
-int wh_ring_log2(const vd_wgrad_desc& d) {
-    const int need = 2 * WH_BP + 2 * wh_hloa(d);
-    int l = 7;
-    while ((1 << l) < need) ++l;
-    return l;
+// ring rows: the window of a step (32 positions + the halo either side) plus the block being written; a power of two where
+// that fits LDS (one-instruction wrap), else exactly what is needed
+int wh_ring_need(const vd_wgrad_desc& d) { return 2 * WH_BP + 2 * wh_hloa(d); }
+int wh_ring_pow2(const vd_wgrad_desc& d) {
+    int r = 128;
+    while (r < wh_ring_need(d)) r *= 2;
+    return r;
 }
-// 128 output channels x two 32-channel chunks where Ci allows it: 24 KB of operand loads per step (16 dout + 8 activation)
-// against 36 KB for 256 x one chunk, and half the dout re-reads over the grid; VD_WGRAD_HALO_BM=256 forces the wide tile
+int wh_ring_need(const vd_wgrad_desc& d);
+int wh_ring_pow2(const vd_wgrad_desc& d);
+int64_t wh_lds_cfg(const vd_wgrad_desc& d, int bm, int rows) {
+    const int npl = (d.flags & VD_STORE_BF16) ? 1 : 2;
+    return (int64_t)2 * npl * WH_BP * bm * 2 + (int64_t)(256 / bm) * npl * (rows + WH_MIR) * 64;
+}
+// 128 output channels x two 32-channel chunks where Ci allows it and the two rings fit LDS: 24 KB of operand loads per step
+// (16 dout + 8 activation) against 36 KB for 256 x one chunk, and half the dout re-reads over the grid;
+// VD_WGRAD_HALO_BM=256 forces the wide tile
 int wh_bm(const vd_wgrad_desc& d) {
     static const int force = getenv("VD_WGRAD_HALO_BM") ? atoi(getenv("VD_WGRAD_HALO_BM")) : 0;
     if (force == 256 && d.Co >= 256) return 256;
-    return (d.Ci % (2 * WH_CH) == 0 || d.Co < 256) ? 128 : 256;
+    const bool fits128 = wh_lds_cfg(d, 128, wh_ring_need(d)) <= 160 * 1024;
+    return (d.Ci % (2 * WH_CH) == 0 && fits128) ? 128 : 256;
 }
 int wh_nch(const vd_wgrad_desc& d) { return 256 / wh_bm(d); }
-int64_t wh_lds(const vd_wgrad_desc& d) {
-    const int npl = (d.flags & VD_STORE_BF16) ? 1 : 2;
-    return (int64_t)2 * npl * WH_BP * wh_bm(d) * 2 + (int64_t)wh_nch(d) * npl * ((1 << wh_ring_log2(d)) + WH_MIR) * 64;
+int64_t wh_lds_rows(const vd_wgrad_desc& d, int rows) { return wh_lds_cfg(d, wh_bm(d), rows); }
+int wh_ring_rows(const vd_wgrad_desc& d) {
+    return wh_lds_rows(d, wh_ring_pow2(d)) <= 160 * 1024 ? wh_ring_pow2(d) : wh_ring_need(d);
 }
+int64_t wh_lds(const vd_wgrad_desc& d) { return wh_lds_rows(d, wh_ring_rows(d)); }
 
-template <int BM, bool BF>
-void launch(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStream_t s) {
+template <int BM, bool BF, bool P2>
+void launch_p(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStream_t s) {
     const int lds = (int)wh_lds(d);
     static int attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_halo<BM, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_halo<BM, BF, P2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_lds = lds;
     }
     const int64_t tiles = vd_cdiv(d.Co, BM) * (d.Ci / ((256 / BM) * WH_CH));
@@ -435,8 +454,14 @@ void launch(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStre
         zd_in = zp - d.in;
         zd_do = zp - d.dout;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_halo<BM, BF>), dim3((unsigned)(tiles * splits)), dim3(512), lds, s, d, dst, qps,
-                       wh_ring_log2(d), wh_hloa(d), zd_in, zd_do);
+    hipLaunchKernelGGL((k_conv_wgrad_halo<BM, BF, P2>), dim3((unsigned)(tiles * splits)), dim3(512), lds, s, d, dst, qps,
+                       wh_ring_rows(d), wh_hloa(d), zd_in, zd_do);
+}
+template <int BM, bool BF>
+void launch(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStream_t s) {
+    const int r = wh_ring_rows(d);
+    if ((r & (r - 1)) == 0) launch_p<BM, BF, true>(d, dst, splits, qps, s);
+    else launch_p<BM, BF, false>(d, dst, splits, qps, s);
 }
 
 }   // namespace
@@ -447,7 +472,7 @@ bool vd_wgrad_halo_ok(const vd_wgrad_desc& d) {
     if (!bf && !(d.flags & VD_MATH_F16X2)) return false;
     if (!bf && (!d.amax_in || !d.amax_dout)) return false;
     if (d.in_scale || d.T != WH_T || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi) return false;
-    if (d.Co < 128 || d.Ci % (wh_nch(d) * WH_CH) != 0 || d.Wi < 5 || d.Hi < 2) return false;
+    if (d.Co < wh_bm(d) || d.Ci % (wh_nch(d) * WH_CH) != 0 || d.Wi < 5 || d.Hi < 2) return false;      // (no half-empty co tile)
     for (int t = 0; t < WH_T; ++t)
         if (d.dz[t] != 0 || d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1) return false;
     if ((int64_t)d.N * (d.Hi + 1) * (d.Wi + 1) >= (1ll << 31) - (1 << 16)) return false;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vd_stem_im2col_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
     "vd_conv_wgrad": (_i, [C.POINTER(WgradDesc), _p, _i64, _p]),
+    "vd_conv_wgrad_uses_halo": (_i, [C.POINTER(WgradDesc)]),
     "vd_stem_im2col": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_pack_weight_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vd_pack_weight_dgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _i, _p]),

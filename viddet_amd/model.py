@@ -93,6 +93,8 @@ class Program:
                     d = args[0]._obj
                     meta = dict(meta or {}, split=bool(d.flags & L.MATH_SPLIT), bf16=bool(d.flags & L.MATH_BF16),
                                 f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)))
+                    if fname == "vd_conv_wgrad":                # the halo-ring kernel (vd_wgrad_halo.hip) or the generic one
+                        meta["wgrad_halo"] = bool(L.load().vd_conv_wgrad_uses_halo(args[0]))
                     if fname == "vd_conv_igemm" and meta.get("bytes"):
                         # operands the fused epilogue reads besides input / weights: the residual (or accumulated
                         # gradient) rows, and the producer's z rows of the fused BatchNorm-backward reductions
@@ -345,18 +347,22 @@ def autotune_desc(d, reps=3):
     _TUNE_CACHE[key] = best
 
 
-def _wgrad_halo_applies(d):
-    """the geometry test of vd_wgrad_halo_ok (vd_wgrad_halo.hip); the library ignores VD_WGRAD_HALO elsewhere, this only
-    keeps launches that cannot use it out of the timing loop"""
-    return d.T == 9 and d.in_stride == 1 and d.Kfr == 1 and d.Hg == d.Hi and d.Wg == d.Wi and d.Co >= 128 and \
-        d.Ci % 32 == 0 and 5 <= d.Wi <= 208 and not d.in_scale
+def _wgrad_halo_applies(d, flags):
+    """would vd_conv_wgrad run the halo-ring kernel (vd_wgrad_halo.hip) for this record with `flags` | VD_WGRAD_HALO?
+    The library ignores the flag elsewhere; this keeps such launches out of the timing loop."""
+    keep = d.flags
+    d.flags = flags | L.WGRAD_HALO
+    try:
+        return bool(L.load().vd_conv_wgrad_uses_halo(C.byref(d)))
+    finally:
+        d.flags = keep
 
 
 def autotune_wgrad_bf16(d, ws_ptr, ws_bytes, reps=2):
     """bf16-stored operands: generic kernel vs the halo ring, timed in place (the flag is ignored where it does not apply)"""
     import os
     d.flags = L.STORE_BF16 | L.MATH_BF16
-    if not _wgrad_halo_applies(d) or os.environ.get("VD_WGRAD_HALO", "1") != "1":
+    if os.environ.get("VD_WGRAD_HALO", "1") != "1" or not _wgrad_halo_applies(d, L.STORE_BF16 | L.MATH_BF16):
         return
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
         d.flags |= L.WGRAD_HALO
@@ -396,7 +402,7 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
         return
     f16 = L.MATH_F16X2 if (d.amax_in and d.amax_dout and not d.in_scale) else L.MATH_SPLIT
     # the halo-ring kernel (vd_wgrad_halo.hip) where the library takes it: 3x3 / stride 1 / Co >= 128, fp16 split
-    halo = L.WGRAD_HALO if (f16 == L.MATH_F16X2 and _wgrad_halo_applies(d) and os.environ.get("VD_WGRAD_HALO", "1") == "1") else 0
+    halo = L.WGRAD_HALO if (f16 == L.MATH_F16X2 and os.environ.get("VD_WGRAD_HALO", "1") == "1" and _wgrad_halo_applies(d, f16)) else 0
     if math in ("split", "split2") or os.environ.get("VD_AUTOTUNE", "1") == "0":
         d.flags = (f16 | halo) if math in ("split2", "auto") else L.MATH_SPLIT
         return
