@@ -1723,10 +1723,12 @@ int wgrad_bm(const vd_wgrad_desc& d) {
 // workgroups resident at once: 2 per CU for the fp32-MFMA tiles, 1 per CU for the split-math tiles (LDS)
 // A weight-gradient workgroup lives for its whole pixel range (0.2-1.3 ms) and, with 8 waves x 256 VGPRs, shares its CU
 // with nothing: a grid that fills all 256 CUs starves the critical-path stream it runs beside - the rocprofv3 timeline
-// showed a 44-block partial-sum reduction crawling through ONE free CU for 0.62 ms.  The grid is therefore sized for
-// 240 CUs (VD_WGRAD_RESERVE, default 16 withheld): +1.0 % on the training step, same-box A/B (688.7 vs 682.0 frames/s).
+// showed a 44-block partial-sum reduction crawling through ONE free CU for 0.62 ms.  Round 1 therefore sized the grid for
+// 240 CUs (VD_WGRAD_RESERVE = 16 withheld: +1.0 % on the training step then, 688.7 vs 682.0 frames/s).  With the BatchNorm
+// reductions fused into the conv epilogues and the 3x3 layers on the halo-ring kernel the same A/B now favours the full
+// chip (round 3, two boxes: reserve 0 / 0 1040-1042 and 1008-1013 frames/s against 1031-1035 and 1001-1004 for 16 / 16).
 int wgrad_slots(const vd_wgrad_desc& d) {
-    static const int reserve = getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 16;
+    static const int reserve = getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 0;
     return (wgrad_split_math(d) && d.Co >= 128) ? 256 - reserve : 512 - 2 * reserve;
 }
 

@@ -301,22 +301,27 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     auto compute = [&](int buf) {
         const char* a3 = As3 + buf * NPL * APL + a_off;
         auto at = [&](int t) { return wrapB(xb + tapB[t]); };         // tap t's ring address: one add, one and (P2)
-        v4i fa[NPL], fb[2][NPL];
+        // operand fragments PF items ahead of the MFMAs that use them (an item = one tap of one 16-position half).  One item
+        // is enough: PF = 2 on the 128-row tile (8 more VGPRs) measured the same within noise on every layer shape
+        // (same-box A/B, tools/wgrad_bench.py) - the LDS round trip is not what the loop waits for.
+        constexpr int PF = 1;
+        v4i fa[NPL], fb[PF + 1][NPL];
         readA(fa, a3, 0);
-        readB(fb[0], at(0), 0);
         constexpr int NI = 2 * WH_T;                     // items: (half kc, tap t)
+#pragma unroll
+        for (int j = 0; j < PF; ++j) readB(fb[j], at(j % WH_T), j / WH_T);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = i % WH_T;
-            if (i + 1 < NI) readB(fb[(i + 1) & 1], at((i + 1) % WH_T), (i + 1) / WH_T);
+            if (i + PF < NI) readB(fb[(i + PF) % (PF + 1)], at((i + PF) % WH_T), (i + PF) / WH_T);
             if (i == WH_T) readA(fa, a3, 1);             // (one register set: the second half's dout fragment is read where
             __builtin_amdgcn_s_setprio(1);               // it is needed - a second set put the kernel over 256 VGPRs)
             if constexpr (BF) {
-                acc[t] = mma<true>(fa[0], fb[i & 1][0], acc[t]);
+                acc[t] = mma<true>(fa[0], fb[i % (PF + 1)][0], acc[t]);
             } else {                                      // smallest partial products first: al*bh, ah*bl, ah*bh
-                acc[t] = mma<false>(fa[1], fb[i & 1][0], acc[t]);
-                acc[t] = mma<false>(fa[0], fb[i & 1][1], acc[t]);
-                acc[t] = mma<false>(fa[0], fb[i & 1][0], acc[t]);
+                acc[t] = mma<false>(fa[1], fb[i % (PF + 1)][0], acc[t]);
+                acc[t] = mma<false>(fa[0], fb[i % (PF + 1)][1], acc[t]);
+                acc[t] = mma<false>(fa[0], fb[i % (PF + 1)][0], acc[t]);
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -479,10 +484,11 @@ bool vd_wgrad_halo_ok(const vd_wgrad_desc& d) {
     return wh_lds(d) <= 160 * 1024;
 }
 
-// split count: the fullest last round of 240 (256 - VD_WGRAD_RESERVE) one-per-CU workgroups, as wgrad_pick_splits
+// split count: the fullest last round of 256 - VD_WGRAD_HALO_RESERVE one-per-CU workgroups, as wgrad_pick_splits
 int vd_wgrad_halo_splits(const vd_wgrad_desc& d) {
     if (d.splits > 0) return d.splits;
-    static const int reserve = getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 16;
+    static const int reserve = getenv("VD_WGRAD_HALO_RESERVE") ? atoi(getenv("VD_WGRAD_HALO_RESERVE"))
+                               : (getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 0);
     const int64_t Q = (int64_t)d.N * (d.Hi + 1) * (d.Wi + 1);
     const int64_t tiles = vd_cdiv(d.Co, wh_bm(d)) * (d.Ci / (wh_nch(d) * WH_CH));
     const int64_t slots = 256 - reserve;
