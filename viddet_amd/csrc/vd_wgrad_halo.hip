@@ -41,10 +41,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef s16x4 __attribute__((address_space(3))) * lds_p;
 
-constexpr int WH_BP = 32;      // padded positions per K-step
+#ifndef VD_WH_SETPRIO
+#define VD_WH_SETPRIO 2        // developer A/B: s_setprio 1 around 0 = nothing, 1 = the whole multiply phase, 2 = every MFMA group
+#endif
+constexpr int WH_BP = 32;      // padded positions per K-step (64 for the bf16-tensor form where LDS allows)
 constexpr int WH_CH = 32;      // input channels per workgroup
 constexpr int WH_T = 9;
-constexpr int WH_MIR = 32;     // ring rows mirrored past the end: one masked address serves the 24 rows a lane reads per step
 
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
     f32x2 v = {a, b};
@@ -76,10 +78,8 @@ __device__ __forceinline__ f32x16 mma(const v4i a, const v4i b, const f32x16 c) 
 // LDS: [2 stages][NPL planes][32 positions][BM co] fp16 (dout; 64-B channel chunks XOR-swizzled with position & 3, as
 // k_conv_wgrad), then per chunk and plane the activation ring [RING + 32 rows][32 ch] fp16, 64 B per row: the 4
 // consecutive rows x 64 B a half-wave's ds_read_b64_tr_b16 touches are 256 contiguous bytes (mod the ring) = all 64 banks.
-// The two waves of a SIMD (w, w + 4) run a step's two phases - [multiply] and [split + store the next tiles] - in opposite
-// order, so one wave's VALU / LDS-store phase sits under its partner's MFMAs instead of both idling the matrix pipe
-// together (vd_conv.hip STAGGER); inside the multiply phase the operand fragments of item i + 1 (an item = one tap of one
-// 16-position half) are read before the MFMAs of item i.
+// Inside the multiply phase the operand fragments of item i + 1 (an item = one tap of one 16-position block) are read before
+// the MFMAs of item i, and every MFMA group runs at s_setprio 1 (same-box A/B: without it the bf16 form loses 5 %).
 // ---------------------------------------------------------------------------------------------------------------------
 struct WhCursor {      // a position of the padded space: column, row within the image (H = the pad row), and the
     int x, y, pr;      // real-pixel index of (n, y, 0)
@@ -87,7 +87,9 @@ struct WhCursor {      // a position of the padded space: column, row within the
 
 // P2: the ring has a power-of-two row count (wrap = one and); otherwise it has exactly the 64 + 2 hloa rows the window
 // needs and wraps by compare - the form that lets the two-chunk tile of a 104-wide map fit LDS (320 rows instead of 512).
-template <int BM, bool BF, bool P2>
+// BP: padded positions per K-step, 32 or 64 (64 halves the barriers and the per-step cursor / request work per MFMA: what the
+// bf16-tensor form, with one MFMA per product block, is bound by: +6 %; the fp16-split form measured the same at both).
+template <int BM, bool BF, bool P2, int BP>
 __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc p, float* __restrict__ dst, const int64_t q_per_split,
                                                             const int ring_rows, const int hloa, const int64_t zd_in,
                                                             const int64_t zd_do) {
@@ -99,19 +101,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     constexpr int TPP = BM / VW;                         // dout lanes per position
     constexpr int RW = 64 / TPP;                         // positions one wave instruction covers
     constexpr int ARP = NT / TPP;                        // positions per pass of the whole workgroup
-    constexpr int APASS = WH_BP / ARP;
-    static_assert(RW >= 1 && APASS >= 1 && APASS * ARP == WH_BP, "dout loader");
+    constexpr int APASS = BP / ARP;
+    static_assert(RW >= 1 && APASS >= 1 && APASS * ARP == BP, "dout loader");
+    constexpr int MIR = BP;                              // ring rows mirrored past the end: one wrapped address serves a lane's BP - 8 rows
     constexpr int XTP = NCH * WH_CH / VW;                // activation lanes per position
-    constexpr int XNT = WH_BP * XTP;                     // lanes that stage the 32 new positions of a step
-    static_assert(XNT <= NT, "activation loader");
-    constexpr int APL = WH_BP * BM * 2;                  // bytes of one dout plane
+    constexpr int XNT = BP * XTP;                        // 16-byte pieces of the BP new positions of a step
+    constexpr int XPASS = XNT > NT ? XNT / NT : 1;       // ... per lane
+    constexpr int XPP = NT / XTP;                        // positions one pass of the workgroup covers
+    static_assert(XPASS * NT == XNT || XNT < NT, "activation loader");
+    constexpr int APL = BP * BM * 2;                     // bytes of one dout plane
     using LT = typename vd_select<BF, v4i, f32x4>::type;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As3 = reinterpret_cast<char*>(smem);           // [2][NPL][32][BM] fp16
     char* Xr = As3 + 2 * NPL * APL;                      // [NCH][NPL][RING + 32][64 B]
     const int RING = ring_rows;                          // a multiple of 32
-    const int XPL = (RING + WH_MIR) * 64;                // bytes of one ring plane
+    const int XPL = (RING + MIR) * 64;                  // bytes of one ring plane
     const int RB = RING * 64;                            // bytes of the ring proper
     auto wrapB = [&](int a) -> int {                     // byte offset in (-RB, 2 RB) -> [0, RB)
         if (P2) return a & (RB - 1);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     const int q_begin = (int)((int64_t)split * q_per_split);
     int q_end = (int)((int64_t)q_begin + q_per_split < Q ? (int64_t)q_begin + q_per_split : Q);
     if (q_end < q_begin) q_end = q_begin;
-    const int nks = (q_end - q_begin + WH_BP - 1) / WH_BP;
+    const int nks = (q_end - q_begin + BP - 1) / BP;
     const int c0 = tile_c * (NCH * WH_CH);
 
     // tap t reads the ring tapB[t] bytes from the centre row
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     // ---- cursors over the padded space: decoded once with divisions, then advanced 32 positions per step with carries.
     // Written without short-circuit conditions: with them hipcc turned the (wave-uniform) dout cursors into a chain of
     // scalar branches around every request.
-    const int step_x = WH_BP % W1, step_y = WH_BP / W1;
+    const int step_x = BP % W1, step_y = BP / W1;
     auto decode = [&](int q) -> WhCursor {
         const unsigned qu = (unsigned)q;
         const unsigned row = qu / (unsigned)W1;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
             if constexpr (BF) ra[i] = *reinterpret_cast<const v4i*>(reinterpret_cast<const __bf16*>(p.dout) + sel);
             else ra[i] = *reinterpret_cast<const f32x4*>(p.dout + sel);
         }
-        aq += WH_BP;
+        aq += BP;
     };
     auto lstoreA = [&](int buf, const LT (&ra)[APASS]) {
         char* a3 = As3 + buf * NPL * APL + (alc & 31) * 2;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
 
     // ---- activation loader: lanes < XNT, one 16-byte piece each: position xj of the step's 32 new ones, channels xc..
     const int xj = tid / XTP, xc = (tid % XTP) * VW;
-    const bool xact = tid < XNT;
+    const bool xact = XNT >= NT || tid < XNT;
     char* const xlane = Xr + (xc >> 5) * (NPL * XPL) + (xc & 31) * 2;      // the lane's chunk ring, its channel bytes
     auto xload_cur = [&](const WhCursor c, bool inrange) -> LT {
         const bool ok = inrange & (c.x < W) & (c.y < H);
@@ -244,26 +249,30 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
         char* r = xlane + row * 64;
         if constexpr (BF) {
             *reinterpret_cast<v4i*>(r) = v;
-            if (row < WH_MIR) *reinterpret_cast<v4i*>(r + RING * 64) = v;
+            if (row < MIR) *reinterpret_cast<v4i*>(r + RING * 64) = v;
         } else {
             v2i h, l;
             split2(v, scl_b, h, l);
             *reinterpret_cast<v2i*>(r) = h;
             *reinterpret_cast<v2i*>(r + XPL) = l;
-            if (row < WH_MIR) {
+            if (row < MIR) {
                 *reinterpret_cast<v2i*>(r + RING * 64) = h;
                 *reinterpret_cast<v2i*>(r + RING * 64 + XPL) = l;
             }
         }
     };
-    // steady-state cursor of the lane's position in the stream of new blocks (block s = positions q_begin + 32 (s+1) + hloa ..)
-    int xq = q_begin + WH_BP + hloa + xj;
-    WhCursor xcur = decode(xq);
-    auto gloadX = [&]() -> LT {
-        const LT v = xload_cur(xcur, xact & ((int64_t)xq < Q));
-        xq += WH_BP;
-        advance(xcur);
-        return v;
+    // steady-state cursors of the lane's positions in the stream of new blocks (block s = positions q_begin + BP (s+1) + hloa ..)
+    int xq = q_begin + BP + hloa + xj;
+    WhCursor xcur[XPASS];
+#pragma unroll
+    for (int k2 = 0; k2 < XPASS; ++k2) xcur[k2] = decode(xq + k2 * XPP);
+    auto gloadX = [&](LT (&xv)[XPASS]) {
+#pragma unroll
+        for (int k2 = 0; k2 < XPASS; ++k2) {
+            xv[k2] = xload_cur(xcur[k2], xact & ((int64_t)(xq + k2 * XPP) < Q));
+            advance(xcur[k2]);
+        }
+        xq += BP;
     };
 
     f32x16 acc[WH_T];
@@ -306,16 +315,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
         // (same-box A/B, tools/wgrad_bench.py) - the LDS round trip is not what the loop waits for.
         constexpr int PF = 1;
         v4i fa[NPL], fb[PF + 1][NPL];
+#if VD_WH_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
         readA(fa, a3, 0);
-        constexpr int NI = 2 * WH_T;                     // items: (half kc, tap t)
+        constexpr int NI = (BP / 16) * WH_T;             // items: (16-position block kc, tap t)
 #pragma unroll
         for (int j = 0; j < PF; ++j) readB(fb[j], at(j % WH_T), j / WH_T);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = i % WH_T;
             if (i + PF < NI) readB(fb[(i + PF) % (PF + 1)], at((i + PF) % WH_T), (i + PF) / WH_T);
-            if (i == WH_T) readA(fa, a3, 1);             // (one register set: the second half's dout fragment is read where
-            __builtin_amdgcn_s_setprio(1);               // it is needed - a second set put the kernel over 256 VGPRs)
+            if (i > 0 && t == 0) readA(fa, a3, i / WH_T); // (one register set: the next block's dout fragment is read where
+#if VD_WH_SETPRIO == 2                                   // it is needed - a second set put the kernel over 256 VGPRs)
+            __builtin_amdgcn_s_setprio(1);
+#endif
             if constexpr (BF) {
                 acc[t] = mma<true>(fa[0], fb[i % (PF + 1)][0], acc[t]);
             } else {                                      // smallest partial products first: al*bh, ah*bl, ah*bh
@@ -323,16 +337,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
                 acc[t] = mma<false>(fa[0], fb[i % (PF + 1)][1], acc[t]);
                 acc[t] = mma<false>(fa[0], fb[i % (PF + 1)][0], acc[t]);
             }
+#if VD_WH_SETPRIO == 2
             __builtin_amdgcn_s_setprio(0);
+#endif
         }
-        xb = wrapB(xb + WH_BP * 64);
+#if VD_WH_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        xb = wrapB(xb + BP * 64);
     };
 
-    // ---- prologue: ring rows [0, 32 + 2 hloa) = positions q_begin - hloa ..; dout tile 0 -> stage 0
-    LT ra[2][APASS];
+    // ---- prologue: ring rows [0, BP + 2 hloa) = positions q_begin - hloa ..; dout tile 0 -> stage 0
+    LT ra[APASS];
     {
-        // four passes of loads in flight per round trip (the ring's first fill is 96 .. 480 positions)
-        const int nfill = WH_BP + 2 * hloa;
+        // four passes of loads in flight per round trip (the ring's first fill is 96 .. 576 positions)
+        const int nfill = BP + 2 * hloa;
         constexpr int PPP = NT / XTP;                    // positions per pass with every lane loading
         const int fj = tid / XTP;
         for (int r0 = 0; r0 < nfill; r0 += 4 * PPP) {
@@ -351,27 +370,29 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
             }
         }
     }
-    gloadA(ra[0]);
-    lstoreA(0, ra[0]);
+    gloadA(ra);
+    lstoreA(0, ra);
     __syncthreads();
-    gloadA(ra[1]);
-    int xrow = wrapB((WH_BP + 2 * hloa + xj) * 64) >> 6; // ring row of the lane's position in block 0
+    int xrow = wrapB((BP + 2 * hloa + xj) * 64) >> 6;    // ring row of the lane's first position in block 0
 
-    // One step: request tile s+2 and block s, multiply tile s, store tile s+1 and block s (read from step s+1 on).
-    // Requests past the range read the zero page and the stage / ring rows they land in are never read, so the loop has no
-    // guards (a guarded request makes hipcc drain vmcnt(0) where paths merge - vd_conv.hip); an odd step count runs one
-    // step on zero dout rows.  The second wave of each SIMD stores its dout rows BEFORE it multiplies (they were requested
-    // a step ago), the first one after: the stagger.  (One copy of the multiply phase: as an if / else of the two orders
-    // hipcc spilled 800 registers of accumulators.)
-    const bool late = (wave & 4) != 0;                   // wave-uniform
+    // One step: request dout tile s+1 and activation block s, multiply tile s, then split + store both (tile s+1 into the other
+    // LDS stage, block s into ring rows nobody reads before the barrier): a whole multiply phase of latency cover with ONE
+    // register set per operand.  Requests past the range read the zero page and the rows they land in are never read, so the
+    // loop has no guards (a guarded request makes hipcc drain vmcnt(0) where paths merge - vd_conv.hip); an odd step count
+    // runs one step on zero dout rows.  (Tried and dropped: the two waves of a SIMD running [multiply] and [split + store] in
+    // opposite order, vd_conv.hip's STAGGER - no difference on any layer shape in a same-box A/B, and it needs a second
+    // register set for the dout tile; as an if / else of the two orders hipcc spilled 800 registers of accumulators.)
     auto step = [&](int u) {
-        gloadA(ra[u & 1]);
-        const LT xv = gloadX();
-        if (late) lstoreA((u + 1) & 1, ra[(u + 1) & 1]);
-        compute(u & 1);
-        if (!late) lstoreA((u + 1) & 1, ra[(u + 1) & 1]);
-        if (xact) xstore_row(xv, xrow);
-        xrow = wrapB((xrow + WH_BP) * 64) >> 6;
+        gloadA(ra);
+        LT xv[XPASS];
+        gloadX(xv);
+        compute(u);
+        lstoreA(u ^ 1, ra);
+        if (xact) {
+#pragma unroll
+            for (int k2 = 0; k2 < XPASS; ++k2) xstore_row(xv[k2], k2 == 0 ? xrow : (wrapB((xrow + k2 * XPP) * 64) >> 6));
+        }
+        xrow = wrapB((xrow + BP) * 64) >> 6;
         __syncthreads();
     };
     for (int ks = 0; ks < nks; ks += 2) {
@@ -409,44 +430,53 @@ const void* zero_page_wh() {
     return zp;
 }
 
-int wh_hloa(const vd_wgrad_desc& d) { return ((d.Wi + 2 + 31) / 32) * 32; }
-// ring rows: the window of a step (32 positions + the halo either side) plus the block being written; a power of two where
-// that fits LDS (one-instruction wrap), else exactly what is needed
-int wh_ring_need(const vd_wgrad_desc& d) { return 2 * WH_BP + 2 * wh_hloa(d); }
-int wh_ring_pow2(const vd_wgrad_desc& d) {
-    int r = 128;
-    while (r < wh_ring_need(d)) r *= 2;
-    return r;
-}
-int wh_ring_need(const vd_wgrad_desc& d);
-int wh_ring_pow2(const vd_wgrad_desc& d);
-int64_t wh_lds_cfg(const vd_wgrad_desc& d, int bm, int rows) {
-    const int npl = (d.flags & VD_STORE_BF16) ? 1 : 2;
-    return (int64_t)2 * npl * WH_BP * bm * 2 + (int64_t)(256 / bm) * npl * (rows + WH_MIR) * 64;
-}
-// 128 output channels x two 32-channel chunks where Ci allows it and the two rings fit LDS: 24 KB of operand loads per step
-// (16 dout + 8 activation) against 36 KB for 256 x one chunk, and half the dout re-reads over the grid;
-// VD_WGRAD_HALO_BM=256 forces the wide tile
-int wh_bm(const vd_wgrad_desc& d) {
-    static const int force = getenv("VD_WGRAD_HALO_BM") ? atoi(getenv("VD_WGRAD_HALO_BM")) : 0;
-    if (force == 256 && d.Co >= 256) return 256;
-    const bool fits128 = wh_lds_cfg(d, 128, wh_ring_need(d)) <= 160 * 1024;
-    return (d.Ci % (2 * WH_CH) == 0 && fits128) ? 128 : 256;
-}
-int wh_nch(const vd_wgrad_desc& d) { return 256 / wh_bm(d); }
-int64_t wh_lds_rows(const vd_wgrad_desc& d, int rows) { return wh_lds_cfg(d, wh_bm(d), rows); }
-int wh_ring_rows(const vd_wgrad_desc& d) {
-    return wh_lds_rows(d, wh_ring_pow2(d)) <= 160 * 1024 ? wh_ring_pow2(d) : wh_ring_need(d);
-}
-int64_t wh_lds(const vd_wgrad_desc& d) { return wh_lds_rows(d, wh_ring_rows(d)); }
+// ---- launch configuration: tile (BM x NCH chunks), positions per step, ring rows ----------------------------------------
+struct WhCfg {
+    int bm, nch, bp, hloa, ring;
+    bool p2, ok;
+    int64_t lds;
+};
 
-template <int BM, bool BF, bool P2>
-void launch_p(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStream_t s) {
-    const int lds = (int)wh_lds(d);
+int64_t wh_lds_bytes(bool bf, int bm, int bp, int rows) {
+    const int npl = bf ? 1 : 2;
+    return (int64_t)2 * npl * bp * bm * 2 + (int64_t)(256 / bm) * npl * (rows + bp) * 64;     // dout stages + rings (+ mirror rows)
+}
+
+WhCfg wh_config(const vd_wgrad_desc& d) {
+    static const int force_bm = getenv("VD_WGRAD_HALO_BM") ? atoi(getenv("VD_WGRAD_HALO_BM")) : 0;
+    static const int force_bp = getenv("VD_WGRAD_HALO_BP") ? atoi(getenv("VD_WGRAD_HALO_BP")) : 0;
+    constexpr int64_t LDS = 160 * 1024;
+    WhCfg c{};
+    const bool bf = d.flags & VD_STORE_BF16;
+    c.hloa = ((d.Wi + 2 + 31) / 32) * 32;                  // halo either side of a step's positions, rounded up
+    // 64 positions per step for bf16 tensors (one MFMA per product block: the step's fixed work is what binds; +6 %), 32 for
+    // the fp16 split (three MFMAs per block: 64 measured the same)
+    const int bp_first = (bf && force_bp != 32) ? 64 : 32;               // (VD_WGRAD_HALO_BP=32: developer A/B of the bf16 form)
+    // 128 output channels x two 32-channel chunks where Ci allows it and the rings fit LDS: 24 KB of operand loads per 32
+    // positions (16 dout + 8 activation) against 36 KB for 256 x one chunk, and half the dout re-reads over the grid
+    for (int bp = bp_first; bp >= 32 && !c.ok; bp -= 32) {
+        const int need = 2 * bp + 2 * c.hloa;              // a step's window (positions + halo either side) + the block being written
+        int bm = (d.Ci % (2 * WH_CH) == 0 && wh_lds_bytes(bf, 128, bp, need) <= LDS) ? 128 : 256;
+        if (force_bm == 256 && d.Co >= 256) bm = 256;
+        if (wh_lds_bytes(bf, bm, bp, need) > LDS) continue;
+        int pow2 = 128;
+        while (pow2 < need) pow2 *= 2;
+        c.bm = bm; c.nch = 256 / bm; c.bp = bp;
+        c.ring = wh_lds_bytes(bf, bm, bp, pow2) <= LDS ? pow2 : need;     // power of two (wrap = one and) where it fits
+        c.p2 = (c.ring & (c.ring - 1)) == 0;
+        c.lds = wh_lds_bytes(bf, bm, bp, c.ring);
+        c.ok = true;
+    }
+    return c;
+}
+
+template <int BM, bool BF, bool P2, int BP>
+void launch_k(const vd_wgrad_desc& d, const WhCfg& c, float* dst, int splits, int64_t qps, hipStream_t s) {
     static int attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_halo<BM, BF, P2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
+    if ((int)c.lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_halo<BM, BF, P2, BP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)c.lds);
+        attr_lds = (int)c.lds;
     }
     const int64_t tiles = vd_cdiv(d.Co, BM) * (d.Ci / ((256 / BM) * WH_CH));
     int64_t zd_in, zd_do;
@@ -459,14 +489,22 @@ void launch_p(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipSt
         zd_in = zp - d.in;
         zd_do = zp - d.dout;
     }
-    hipLaunchKernelGGL((k_conv_wgrad_halo<BM, BF, P2>), dim3((unsigned)(tiles * splits)), dim3(512), lds, s, d, dst, qps,
-                       wh_ring_rows(d), wh_hloa(d), zd_in, zd_do);
+    hipLaunchKernelGGL((k_conv_wgrad_halo<BM, BF, P2, BP>), dim3((unsigned)(tiles * splits)), dim3(512), (size_t)c.lds, s, d, dst, qps,
+                       c.ring, c.hloa, zd_in, zd_do);
 }
 template <int BM, bool BF>
-void launch(const vd_wgrad_desc& d, float* dst, int splits, int64_t qps, hipStream_t s) {
-    const int r = wh_ring_rows(d);
-    if ((r & (r - 1)) == 0) launch_p<BM, BF, true>(d, dst, splits, qps, s);
-    else launch_p<BM, BF, false>(d, dst, splits, qps, s);
+void launch(const vd_wgrad_desc& d, const WhCfg& c, float* dst, int splits, int64_t qps, hipStream_t s) {
+    if constexpr (BF) {            // (the fp16-split form measured the same at 32 and 64 positions per step: one instantiation)
+        if (c.bp == 64) {
+            if (c.p2) launch_k<BM, BF, true, 64>(d, c, dst, splits, qps, s);
+            else launch_k<BM, BF, false, 64>(d, c, dst, splits, qps, s);
+            return;
+        }
+    }
+    {
+        if (c.p2) launch_k<BM, BF, true, 32>(d, c, dst, splits, qps, s);
+        else launch_k<BM, BF, false, 32>(d, c, dst, splits, qps, s);
+    }
 }
 
 }   // namespace
@@ -477,11 +515,13 @@ bool vd_wgrad_halo_ok(const vd_wgrad_desc& d) {
     if (!bf && !(d.flags & VD_MATH_F16X2)) return false;
     if (!bf && (!d.amax_in || !d.amax_dout)) return false;
     if (d.in_scale || d.T != WH_T || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi) return false;
-    if (d.Co < wh_bm(d) || d.Ci % (wh_nch(d) * WH_CH) != 0 || d.Wi < 5 || d.Hi < 2) return false;      // (no half-empty co tile)
+    if (d.Wi < 5 || d.Hi < 2 || d.Ci % WH_CH != 0) return false;
     for (int t = 0; t < WH_T; ++t)
         if (d.dz[t] != 0 || d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1) return false;
-    if ((int64_t)d.N * (d.Hi + 1) * (d.Wi + 1) >= (1ll << 31) - (1 << 16)) return false;
-    return wh_lds(d) <= 160 * 1024;
+    if ((int64_t)d.N * (d.Hi + 1) * (d.Wi + 1) >= (1ll << 31) - (1 << 17)) return false;
+    const WhCfg c = wh_config(d);
+    if (!c.ok || d.Co < c.bm || d.Ci % (c.nch * WH_CH) != 0) return false;          // (no half-empty co tile)
+    return c.bp / (d.Wi + 1) < 2 * (d.Hi + 1);             // the position cursors carry over at most two images per step
 }
 
 // split count: the fullest last round of 256 - VD_WGRAD_HALO_RESERVE one-per-CU workgroups, as wgrad_pick_splits
@@ -490,7 +530,8 @@ int vd_wgrad_halo_splits(const vd_wgrad_desc& d) {
     static const int reserve = getenv("VD_WGRAD_HALO_RESERVE") ? atoi(getenv("VD_WGRAD_HALO_RESERVE"))
                                : (getenv("VD_WGRAD_RESERVE") ? atoi(getenv("VD_WGRAD_RESERVE")) : 0);
     const int64_t Q = (int64_t)d.N * (d.Hi + 1) * (d.Wi + 1);
-    const int64_t tiles = vd_cdiv(d.Co, wh_bm(d)) * (d.Ci / (wh_nch(d) * WH_CH));
+    const WhCfg cfg = wh_config(d);
+    const int64_t tiles = vd_cdiv(d.Co, cfg.bm) * (d.Ci / (cfg.nch * WH_CH));
     const int64_t slots = 256 - reserve;
     int64_t s = 1;
     double best = -1.0;
@@ -500,7 +541,7 @@ int vd_wgrad_halo_splits(const vd_wgrad_desc& d) {
         const double fill = x / (double)vd_cdiv(tiles * c, slots);
         if (fill > best + 0.02) { best = fill; s = c; }
     }
-    const int64_t maxs = vd_cdiv(Q, 16 * WH_BP);        // >= 16 K-steps per workgroup (the ring prologue is ~3-8 steps of loads)
+    const int64_t maxs = vd_cdiv(Q, 16 * WH_BP);        // >= 512 positions per workgroup (the ring's first fill is 100-480)
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
@@ -508,14 +549,15 @@ int vd_wgrad_halo_splits(const vd_wgrad_desc& d) {
 }
 
 void vd_wgrad_halo_launch(const vd_wgrad_desc& d, float* dst, int splits, hipStream_t s) {
+    const WhCfg c = wh_config(d);
     const int64_t Q = (int64_t)d.N * (d.Hi + 1) * (d.Wi + 1);
-    const int64_t qps = vd_cdiv(vd_cdiv(Q, splits), 2 * WH_BP) * (2 * WH_BP);      // even step counts
+    const int64_t qps = vd_cdiv(vd_cdiv(Q, splits), 2 * c.bp) * (2 * c.bp);      // even step counts
     const bool bf = d.flags & VD_STORE_BF16;
-    if (wh_bm(d) == 256) {
-        if (bf) launch<256, true>(d, dst, splits, qps, s);
-        else launch<256, false>(d, dst, splits, qps, s);
+    if (c.bm == 256) {
+        if (bf) launch<256, true>(d, c, dst, splits, qps, s);
+        else launch<256, false>(d, c, dst, splits, qps, s);
     } else {
-        if (bf) launch<128, true>(d, dst, splits, qps, s);
-        else launch<128, false>(d, dst, splits, qps, s);
+        if (bf) launch<128, true>(d, c, dst, splits, qps, s);
+        else launch<128, false>(d, c, dst, splits, qps, s);
     }
 }
