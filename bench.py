@@ -173,6 +173,10 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    if os.environ.get("VD_MAIN_PRIO"):          # developer A/B: the whole step on a stream of this priority (-1 = high)
+        _ms = torch.cuda.Stream(priority=int(os.environ["VD_MAIN_PRIO"]))
+        _ms.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(_ms)
     for _ in range(a.warmup):
         step()
     sync()

@@ -1679,7 +1679,7 @@ class YOLOV3(object):
         # so the only edges are  dz ready -> wgrad  (event) and  wgrad done -> dz scratch reuse  (event; the dz
         # scratch is double-buffered), plus one join before the optimiser.  Tails of one GEMM fill with the other.
         bwd, seg = [], Program()
-        side = torch.cuda.Stream() if self.overlap_wgrad else None
+        side = torch.cuda.Stream(priority=int(__import__('os').environ.get('VD_SIDE_PRIO', '0'))) if self.overlap_wgrad else None
         ws_w = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if side is not None else ws
         dz_bufs = [bufs['dz'], bufs['dz2']]
         dz_free = [None, None]             # event after which dz_bufs[i] may be overwritten
@@ -2172,7 +2172,7 @@ class YOLOV3(object):
         # ---- backward (the schedule of _build_train: wgrad GEMMs on a side stream, double-buffered dz scratch, skip
         # gradients by alias, bucketed all-reduce behind the weight gradients)
         bwd, seg = [], Program()
-        side = torch.cuda.Stream() if self.overlap_wgrad else None
+        side = torch.cuda.Stream(priority=int(__import__('os').environ.get('VD_SIDE_PRIO', '0'))) if self.overlap_wgrad else None
         ws_w = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if side is not None else ws
         dz_bufs, dz_free, n_dz, last_side = [bufs['dz'], bufs['dz2']], [None, None], [0], [None]
 
