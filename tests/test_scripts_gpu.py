@@ -58,12 +58,23 @@ def test_detect_script_writes_the_oracles_rows(tmp_path, capsys):
         with open(pred_dir / (fid + ".txt")) as f:
             lines = [ln.rstrip().split(",") for ln in f if ln.strip()]
         assert len(lines) == len(want), (idx, len(lines), len(want))
-        for ln, w in zip(lines, want):
-            assert ln[0] == img_path and int(ln[1]) == w[0]
-            got = np.array([float(v) for v in ln[2:7]])
-            # fp32 cannot rank scores closer than ~1e-6: a swap of two such neighbours shows up as a class / box
-            # mismatch here and would be a fixture accident, not an error (not seen with this seed)
-            assert abs(got[0] - w[1]) < 1e-3 and np.abs(got[1:] - np.array(w[2:])).max() < 1e-4, (idx, ln, w)
+        # fp32 cannot rank scores closer than ~1e-6 (tests/util.py assert_rows_match): inside a run of reference scores that
+        # close, the written rows may come in either order - which one depends on the tiles the autotuner picked (seen once
+        # on the GPU box: classes 9 / 1 swapped at one rank).  Everything else is compared rank by rank.
+        j = 0
+        while j < len(want):
+            e = j + 1
+            while e < len(want) and abs(want[e][1] - want[e - 1][1]) < 1e-6:
+                e += 1
+            left = list(range(j, e))
+            for ln in lines[j:e]:
+                assert ln[0] == img_path
+                got = np.array([float(v) for v in ln[2:7]])
+                hit = [r for r in left if int(ln[1]) == want[r][0] and abs(got[0] - want[r][1]) < 1e-3 and
+                       np.abs(got[1:] - np.array(want[r][2:])).max() < 1e-4]
+                assert hit, (idx, ln, [want[r] for r in left])
+                left.remove(hit[0])
+            j = e
         nrows += len(want)
         pred = np.array([[w[0], w[1]] + list(w[2:]) for w in want], dtype=np.float64).reshape(-1, 6)
         metric.update([pred[:, 2:6]], [pred[:, 0]], [pred[:, 1]], [gt[:, :4] / size], [gt[:, 4]], [gt[:, 5]])
