@@ -48,10 +48,13 @@ def test_fixed_batch_loss_falls_and_the_trained_net_finds_its_boxes():
     print("summed loss: step 0 %.1f, 10 %.1f, 50 %.1f, 149 %.1f" % (tot[0], tot[10], tot[50], tot[-1]))
     assert np.all(np.isfinite(hist)) and bool(torch.isfinite(net.weights).all()) and bool(torch.isfinite(net.running).all())
     assert tot[10] < 0.8 * tot[0] and tot[50] < 0.5 * tot[0] and tot[-1] < 0.25 * tot[0], tot[[0, 10, 50, -1]]
-    # smoothed over windows of 25 steps the loss falls monotonically until it reaches its plateau under this learning rate
-    # (which kernels the autotuner picks moves the tail by a few per cent from run to run)
+    # smoothed over windows of 25 steps the loss falls steeply, then reaches its plateau under this learning rate.  WHERE the
+    # plateau starts and how it wobbles depends on the kernels in use (tile choices and summation orders move the tail by a
+    # few per cent: one build had windows 19.18, 19.26, 19.33, 18.32 where another fell monotonically), so the property is:
+    # the first two windows fall, and from then on no window is more than 5 % above the lowest one before it
     w = tot[:150].reshape(6, 25).mean(axis=1)
-    assert np.all(np.diff(w[:4]) < 0) and w[-1] < 1.15 * w.min(), w
+    assert w[1] < 0.5 * w[0] and w[2] < w[1], w
+    assert all(w[i] <= 1.05 * w[:i].min() for i in range(3, 6)) and w[-1] < 1.15 * w.min(), w
     # inference path on the training frames: every ground-truth box is found by a detection with IoU > 0.5
     ids, sc, bx = [t.cpu().numpy() for t in net(dev(x))]
     from viddet_amd.bbox import bbox_iou
