@@ -516,6 +516,8 @@ bool vd_wgrad_halo_ok(const vd_wgrad_desc& d) {
     if (!bf && (!d.amax_in || !d.amax_dout)) return false;
     if (d.in_scale || d.T != WH_T || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi) return false;
     if (d.Wi < 5 || d.Hi < 2 || d.Ci % WH_CH != 0) return false;
+    const int vw = bf ? 8 : 4;                             // channels per 16-byte load: rows and tiles must be whole loads
+    if (d.Co % vw != 0 || d.ldd % vw != 0) return false;
     for (int t = 0; t < WH_T; ++t)
         if (d.dz[t] != 0 || d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1) return false;
     if ((int64_t)d.N * (d.Hi + 1) * (d.Wi + 1) >= (1ll << 31) - (1 << 17)) return false;
