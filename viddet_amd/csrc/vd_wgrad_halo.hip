@@ -10,9 +10,10 @@
 // per pixel step: a 3x3 layer reads every activation pixel nine times (once per tap tile) and every dout pixel Ci*9/128
 // times - 48 KB into the CU per 32-pixel step against 1536 matrix-pipe cycles, 31 B/clk/CU, which is the rate the guide
 // measures for L2-resident gathers (MI355X_MICROARCH.md, "Indexed rows"): the kernel sits on the CU's load path.
-// Here a workgroup owns BM output channels x (9 taps x 32 input channels): the dout tile of a pixel step is shared by the
-// nine taps, and the 32-channel activation rows enter LDS once, into a RING indexed by pixel position; tap t reads the ring
-// at row offset dy*(W+1) + dx.  36 KB (BM = 256) per 3456 matrix-pipe cycles: 10 B/clk/CU.
+// Here a workgroup owns BM output channels x (9 taps x NCH chunks of 32 input channels), BM x NCH = 128 x 2 or 256 x 1: the
+// dout tile of a pixel step is shared by the nine taps and the chunks, and the activation rows enter LDS once, into a RING
+// indexed by pixel position; tap t reads the ring at row offset dy*(W+1) + dx.  24 KB (128 x 2: 16 dout + 8 activation) or
+// 36 KB (256 x 1) per 3456 matrix-pipe cycles: 7-10 B/clk/CU.
 //
 // Borders without masks: the reduction runs over a PADDED position space q = (n*(H+1) + y)*(W+1) + x with one pad column
 // per image row and one pad row per image.  Every out-of-image tap read lands on a pad position (x-1 at x = 0 is the
@@ -75,8 +76,8 @@ __device__ __forceinline__ f32x16 mma(const v4i a, const v4i b, const f32x16 c) 
 // Eight waves.  BM = 256: wave w owns output channels 32 w .. of ONE 32-channel chunk of `in`; BM = 128: waves 0-3 and
 // 4-7 own the same 128 output channels and two neighbouring chunks (NCH = 2), so a 128-channel layer still runs two
 // waves per SIMD on one dout tile.  Each wave: nine 32x32 accumulators (144 registers).
-// LDS: [2 stages][NPL planes][32 positions][BM co] fp16 (dout; 64-B channel chunks XOR-swizzled with position & 3, as
-// k_conv_wgrad), then per chunk and plane the activation ring [RING + 32 rows][32 ch] fp16, 64 B per row: the 4
+// LDS: [2 stages][NPL planes][BP positions][BM co] fp16 (dout; 64-B channel chunks XOR-swizzled with position & 3, as
+// k_conv_wgrad), then per chunk and plane the activation ring [RING + BP rows][32 ch] fp16, 64 B per row: the 4
 // consecutive rows x 64 B a half-wave's ds_read_b64_tr_b16 touches are 256 contiguous bytes (mod the ring) = all 64 banks.
 // Inside the multiply phase the operand fragments of item i + 1 (an item = one tap of one 16-position block) are read before
 // the MFMAs of item i, and every MFMA group runs at s_setprio 1 (same-box A/B: without it the bf16 form loses 5 %).
@@ -85,7 +86,7 @@ struct WhCursor {      // a position of the padded space: column, row within the
     int x, y, pr;      // real-pixel index of (n, y, 0)
 };
 
-// P2: the ring has a power-of-two row count (wrap = one and); otherwise it has exactly the 64 + 2 hloa rows the window
+// P2: the ring has a power-of-two row count (wrap = one and); otherwise it has exactly the 2 BP + 2 hloa rows the window
 // needs and wraps by compare - the form that lets the two-chunk tile of a 104-wide map fit LDS (320 rows instead of 512).
 // BP: padded positions per K-step, 32 or 64 (64 halves the barriers and the per-step cursor / request work per MFMA: what the
 // bf16-tensor form, with one MFMA per product block, is bound by: +6 %; the fp16-split form measured the same at both).
