@@ -370,6 +370,21 @@ def main():
             extra["vd_conv_wgrad"]["by_kernel"] = {
                 k_: {"launches": c[2], "ms": round(c[1], 3), "tflops": round(c[0] / (c[1] * 1e-3) / 1e12, 1),
                      "algorithmic_gb_s": round(c[3] / (c[1] * 1e-3) / 1e9, 0)} for k_, c in cls.items()}
+            # roofline of the halo-ring kernel, priced like k_conv_igemm: the dense MFMA peak of its arithmetic (three f16 MFMAs
+            # per fp32 product block, or one bf16 MFMA on bf16 tensors); traffic = bytes leaving the L2s per launch from the
+            # committed PMC passes of this very command
+            h = extra["vd_conv_wgrad"]["by_kernel"].get("halo_3x3s1")
+            if h:
+                pk = PEAK_BF16_MFMA_TFLOPS if (a.dtype == "bf16" or a.storage == "bf16") else PEAKS["f16x2"]
+                h["roofline"] = {"bound": "mfma", "achieved": h["tflops"], "peak": round(pk, 1), "unit": "TFLOP/s",
+                                 "frac": round(h["tflops"] / pk, 4), "traffic": None}
+                try:
+                    if train and B == 64 and S == 416 and C == 80 and a.storage != "bf16":
+                        import glob
+                        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_b64_416_pmc_traffic.json")))[-1]))
+                        h["roofline"]["traffic"] = round(pm["k_conv_wgrad_halo"]["hbm_mb_corrected"], 1)
+                except Exception:
+                    pass
         extra["conv_ms_per_step"] = round(sum(v[1] for k, v in agg.items() if k.startswith("vd_")), 3)
         if a.detail:
             with open(a.detail, "w") as f:

@@ -45,6 +45,49 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.vd_sgd_momentum(None, None, None, 10, 0.1, 0.9, 0.0, 1.0, None) == -1
 
 
+def test_halo_weight_gradient_dispatch_rules_without_touching_the_gpu():
+    """vd_conv_wgrad_uses_halo / vd_conv_wgrad_ws_bytes are host logic (include/viddet_hip.h VD_WGRAD_HALO): which launches
+    take the halo-ring kernel of vd_wgrad_halo.hip, and that the workspace query follows the kernel's own split count."""
+    from viddet_amd import lib as L, ops
+    lib = L.load()
+
+    def desc(n, ci, h, w, co, k=3, stride=1, flags=L.MATH_F16X2 | L.WGRAD_HALO, amax=True, ldd=None):
+        d = L.WgradDesc()
+        pad = k // 2
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.Co, d.ldd = n, h, w, ci, ho, wo, co, (co if ldd is None else ldd)
+        d.in_stride, d.Kfr, d.flags = stride, 1, flags
+        ops._set_taps(d, ops.fwd_taps(k, pad))
+        if amax:
+            d.amax_in = d.amax_dout = 16                    # only compared with NULL
+        return d
+
+    uses = lambda d: lib.vd_conv_wgrad_uses_halo(ctypes.byref(d))
+    assert uses(desc(64, 256, 26, 26, 512)) == 1             # the Darknet-53 3x3 layers
+    assert uses(desc(64, 64, 104, 104, 128)) == 1            # 104-wide map: the ring that wraps by compare
+    assert uses(desc(64, 512, 13, 13, 1024, flags=L.STORE_BF16 | L.MATH_BF16 | L.WGRAD_HALO, amax=False)) == 1
+    assert uses(desc(64, 256, 26, 26, 512, flags=L.MATH_F16X2)) == 0                        # flag not set
+    assert uses(desc(64, 256, 26, 26, 512, flags=L.MATH_SPLIT | L.WGRAD_HALO)) == 0         # another arithmetic
+    assert uses(desc(64, 256, 26, 26, 512, amax=False)) == 0                                # fp16 split without max-abs slots
+    assert uses(desc(64, 256, 52, 52, 512, stride=2)) == 0                                  # stride 2
+    assert uses(desc(64, 512, 26, 26, 256, k=1)) == 0                                       # 1x1
+    assert uses(desc(64, 32, 208, 208, 64)) == 0                                            # fewer than 128 output channels
+    assert uses(desc(64, 32, 52, 52, 128)) == 0                                             # one chunk would need the 256-row tile
+    assert uses(desc(64, 32, 52, 52, 256)) == 1                                             # ... which Co = 256 fills
+    assert uses(desc(2, 64, 26, 26, 132, flags=L.STORE_BF16 | L.MATH_BF16 | L.WGRAD_HALO, amax=False)) == 0   # rows not whole 16-byte loads
+    assert uses(desc(64, 64, 4, 4, 128)) == 0                                               # narrower than the cursors handle
+    # the workspace is the kernel's slab array: splits x Co x 9 Ci floats, a whole number of slabs, and it differs from the
+    # generic kernel's (other split count) - a caller must ask with the flags of the launch
+    d = desc(64, 256, 26, 26, 512)
+    need = lib.vd_conv_wgrad_ws_bytes(ctypes.byref(d))
+    slab = 512 * 9 * 256 * 4
+    assert need > 0 and need % slab == 0 and need // slab <= 512
+    d.splits = 5
+    assert lib.vd_conv_wgrad_ws_bytes(ctypes.byref(d)) == 5 * slab
+    d.splits = 1
+    assert lib.vd_conv_wgrad_ws_bytes(ctypes.byref(d)) == 0                                 # one range: straight into dwp
+
+
 @pytest.mark.parametrize("k,pad,stride,hi", [(3, 1, 1, 8), (1, 0, 1, 5), (3, 1, 2, 8), (3, 1, 2, 9)])
 def test_dgrad_plans_reproduce_conv_backward(k, pad, stride, hi):
     """Execute the tap plans with plain numpy loops and compare with the oracle's conv backward."""
