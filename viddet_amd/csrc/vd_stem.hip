@@ -247,6 +247,66 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
     }
 }
 
+// Weight gradient, second form: one workgroup = FOUR image rows (a wave each), the frame window they read - three channels
+// x six rows (y0 - 1 .. y0 + 4) x (W + 2) columns, zero outside the frame - staged ONCE in LDS.  The first form's B operand
+// is a gather of 27 different (channel, row, column) addresses per half-wave and MFMA step, i.e. 27 cache lines through the
+// CU's address path for 256 bytes of dz: the kernel ran at 2.5 TB/s of its 1.4 GB.  Here the B operand is one ds_read_b32 per
+// step at a per-lane base plus an immediate (row pitch = 4 mod 32 floats: the 27 lanes of a half-wave fall on 27 different
+// banks), the dz rows stream as before, and the four waves' tiles are summed in LDS (wave order) into ONE partial tile per
+// workgroup.  part: [N * ceil(H / 4)][32 co][32 k].
+constexpr int SROWS = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem_wgrad_rows(const float* __restrict__ x, const T* __restrict__ dz, int ldd,
+                                                         float* __restrict__ part, int N, int H, int W, int P) {
+    extern __shared__ float win[];                    // [3][SROWS + 2][P]; afterwards [4][32 * 32] for the wave tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int groups = (H + SROWS - 1) / SROWS;
+    const int n = blockIdx.x / groups, y0 = (blockIdx.x % groups) * SROWS;
+    const int64_t HW = (int64_t)H * W;
+    const float* xn = x + (int64_t)n * 3 * HW;
+    for (int i = tid; i < 3 * (SROWS + 2) * P; i += 256) {
+        const int col = i % P - 1, rr = i / P;        // rr = c * (SROWS + 2) + r
+        const int c = rr / (SROWS + 2), iy = y0 - 1 + rr % (SROWS + 2);
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)col < (unsigned)W;
+        win[i] = ok ? xn[(int64_t)c * HW + (int64_t)iy * W + col] : 0.f;
+    }
+    __syncthreads();
+    const int k = lane & 31, par = lane >> 5;
+    const bool k_ok = k < SK;
+    const int c = k_ok ? k % 3 : 0, tap = k_ok ? k / 3 : 0;
+    const int y = y0 + wave;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (y < H) {                                       // wave-uniform
+        // window index of (channel c, row y + dy, column x + dx) for x = par: + 2 per step
+        const float* b0 = win + (c * (SROWS + 2) + wave + tap / 3) * P + (tap % 3) + par;
+        const T* a0 = dz + ((int64_t)n * HW + (int64_t)y * W + par) * ldd + k;          // k doubles as co for the A operand
+        constexpr int UNR = 8;
+        for (int x0 = 0; x0 < W; x0 += 2 * UNR) {
+            float a[UNR], b[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool in = x0 + 2 * u + par < W;
+                a[u] = in ? (float)a0[(int64_t)(x0 + 2 * u) * ldd] : 0.f;
+                b[u] = (in && k_ok) ? b0[x0 + 2 * u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // the window is dead: its memory takes the four wave tiles
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        win[wave * (SC * 32) + co * 32 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    float* dst = part + (int64_t)blockIdx.x * (SC * 32);
+    for (int i = tid; i < SC * 32; i += 256)
+        dst[i] = ((win[i] + win[SC * 32 + i]) + win[2 * SC * 32 + i]) + win[3 * SC * 32 + i];
+}
+
 // dst[chunk][i] = sum of part[q][i] over the chunk's slabs, in slab order; gridDim.y chunks (one for the final pass)
 __global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int nparts, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // 32 x 32 outputs
@@ -297,12 +357,32 @@ int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N
     return VD_OK;
 }
 
-int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W) {
+// row pitch of the LDS window: >= W + 2 and = 4 mod 32 floats (bank spread of the 27 operand lanes)
+static int stem_rows_pitch(int W) {
+    int p = W + 2;
+    while (p % 32 != 4) ++p;
+    return p;
+}
+static int64_t stem_rows_lds(int W) {
+    const int64_t win = (int64_t)3 * (SROWS + 2) * stem_rows_pitch(W) * 4, tiles = (int64_t)4 * SC * 32 * 4;
+    return win > tiles ? win : tiles;
+}
+// the row form (k_stem_wgrad_rows) where its window fits 64 KB of LDS (W <= 900); VD_STEM_WGRAD_ROWS=0: developer A/B
+static bool stem_rows_ok(int W) {
+    static const int on = getenv("VD_STEM_WGRAD_ROWS") ? atoi(getenv("VD_STEM_WGRAD_ROWS")) : 1;
+    return on && stem_rows_lds(W) <= 64 * 1024;
+}
+static int64_t stem_run_waves(int N, int H, int W) {
     const int64_t P = (int64_t)N * H * W;
     int64_t waves = vd_cdiv(P, 256);                 // >= 128 MFMA steps per wave
     if (waves > STEM_WG_WAVES) waves = STEM_WG_WAVES;
-    waves = vd_cdiv(waves, 4) * 4;
-    return (waves + STEM_RED_CHUNKS) * SC * 32 * (int64_t)sizeof(float);
+    return vd_cdiv(waves, 4) * 4;
+}
+
+int64_t vd_stem_wgrad_ws_bytes(int N, int H, int W) {
+    const int64_t tiles_rows = (int64_t)N * vd_cdiv(H, SROWS), tiles_run = stem_run_waves(N, H, W);
+    const int64_t tiles = tiles_rows > tiles_run ? tiles_rows : tiles_run;       // either form's partial tiles
+    return (tiles + STEM_RED_CHUNKS) * SC * 32 * (int64_t)sizeof(float);
 }
 
 static int stem_wgrad_any(const float* x_nchw, const void* dz, int dz_bf16, int ldd, float* dwp, int N, int H, int W, void* ws,
@@ -313,20 +393,32 @@ static int stem_wgrad_any(const float* x_nchw, const void* dz, int dz_bf16, int 
         vd_set_error("vd_stem_wgrad: workspace %lld < %lld", (long long)ws_bytes, (long long)need);
         return VD_EWORKSPACE;
     }
-    const int64_t P = (int64_t)N * H * W;
-    const int64_t waves = need / (SC * 32 * (int64_t)sizeof(float)) - STEM_RED_CHUNKS;
-    int64_t ppw = vd_cdiv(P, waves);
-    ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels
     hipStream_t s = (hipStream_t)stream;
-    if (dz_bf16)
-        hipLaunchKernelGGL(k_stem_wgrad<__bf16>, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, (const __bf16*)dz, ldd, (float*)ws,
-                           N, H, W, ppw);
-    else
-        hipLaunchKernelGGL(k_stem_wgrad<float>, dim3((unsigned)(waves / 4)), dim3(256), 0, s, x_nchw, (const float*)dz, ldd, (float*)ws,
-                           N, H, W, ppw);
+    int64_t tiles;
+    if (stem_rows_ok(W)) {
+        tiles = (int64_t)N * vd_cdiv(H, SROWS);
+        const int P = stem_rows_pitch(W), lds = (int)stem_rows_lds(W);
+        if (dz_bf16)
+            hipLaunchKernelGGL(k_stem_wgrad_rows<__bf16>, dim3((unsigned)tiles), dim3(256), lds, s, x_nchw, (const __bf16*)dz, ldd,
+                               (float*)ws, N, H, W, P);
+        else
+            hipLaunchKernelGGL(k_stem_wgrad_rows<float>, dim3((unsigned)tiles), dim3(256), lds, s, x_nchw, (const float*)dz, ldd,
+                               (float*)ws, N, H, W, P);
+    } else {
+        const int64_t P = (int64_t)N * H * W;
+        tiles = stem_run_waves(N, H, W);
+        int64_t ppw = vd_cdiv(P, tiles);
+        ppw = vd_cdiv(ppw, 2) * 2;                       // even: a step is two pixels
+        if (dz_bf16)
+            hipLaunchKernelGGL(k_stem_wgrad<__bf16>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, x_nchw, (const __bf16*)dz, ldd, (float*)ws,
+                               N, H, W, ppw);
+        else
+            hipLaunchKernelGGL(k_stem_wgrad<float>, dim3((unsigned)(tiles / 4)), dim3(256), 0, s, x_nchw, (const float*)dz, ldd, (float*)ws,
+                               N, H, W, ppw);
+    }
     VD_CHECK_LAUNCH("vd_stem_wgrad");
-    float* lvl1 = (float*)ws + waves * (SC * 32);
-    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, STEM_RED_CHUNKS), dim3(256), 0, s, (const float*)ws, (int)waves, lvl1);
+    float* lvl1 = (float*)ws + tiles * (SC * 32);
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, STEM_RED_CHUNKS), dim3(256), 0, s, (const float*)ws, (int)tiles, lvl1);
     VD_CHECK_LAUNCH("vd_stem_wgrad/reduce1");
     hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3(4, 1), dim3(256), 0, s, (const float*)lvl1, STEM_RED_CHUNKS, dwp);
     VD_CHECK_LAUNCH("vd_stem_wgrad/reduce2");
