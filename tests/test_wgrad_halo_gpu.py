@@ -147,3 +147,36 @@ def test_halo_wgrad_from_bf16_operands(case):
     ops.unpack_weight(dwp, dw)
     torch.cuda.synchronize()
     assert maxdiff(dw.cpu().numpy(), dw_ref) < TOL * np.sqrt(n * h * w)       # exact products, fp32 sums
+
+
+def test_halo_wgrad_random_geometries_against_the_generic_kernel():
+    """Seeded sweep over map sizes, channel counts and split counts - every ring size, both tiles, ranges that start and end
+    anywhere in an image - against k_conv_wgrad on the same operands (same arithmetic, another summation order: agreement to
+    a few fp32 roundings of the sum), fp32 and bf16 tensors.  A wrong ring row, a stale mirror row or a misplaced pad position
+    shows up as an O(1) difference."""
+    from viddet_amd import ops
+    rng = np.random.default_rng(2024)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    tried = 0
+    for _ in range(48):
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(2, 61)), int(rng.integers(5, 121))
+        ci = int(rng.choice([32, 64, 96, 128, 192]))
+        co = int(rng.choice([128, 160, 256, 288, 384]))
+        splits = int(rng.choice([0, 0, 1, 2, 3, 5, 7]))
+        x = torch.randn(n, h, w, ci, device="cuda")
+        dy = torch.randn(n, h, w, co, device="cuda")
+        for bf in (False, True):
+            xx, dd = (x.to(BF), dy.to(BF)) if bf else (x, dy)
+            mode_h, mode_g = ("halo", False) if bf else ("f16x2h", "f16x2")
+            if not _uses_halo(xx, dd, co, mode_h):
+                continue
+            tried += 1
+            a = torch.full((co, 9 * ci), 3.0, device="cuda")
+            b = torch.full((co, 9 * ci), 4.0, device="cuda")
+            ops.conv_wgrad(xx, dd, a, ws, k=3, stride=1, pad=1, Co=co, splits=splits, split=mode_h)
+            ops.conv_wgrad(xx, dd, b, ws, k=3, stride=1, pad=1, Co=co, split=mode_g)
+            torch.cuda.synchronize()
+            err = float((a - b).abs().max())
+            assert err < 2e-4 * np.sqrt(n * h * w), (n, h, w, ci, co, splits, bf, err)
+    assert tried >= 40, tried
