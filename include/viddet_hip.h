@@ -13,6 +13,9 @@
  *    owned by the caller; pointers are raw device addresses.
  *  - `stream` is a hipStream_t passed as void*; ordering is by stream only; calls are
  *    asynchronous and re-entrant.
+ *  - ONE device per process (the design is one process per GPU): the library caches the device
+ *    address of its resident zero pages and its kernels' dynamic-LDS attributes in process-wide statics the first time
+ *    an entry point runs; a process that drove a second device through it would read the first device's addresses.
  *  - activations are NHWC fp32 (bf16 where stated); conv weights arrive in the reference's OIHW
  *    layout and are re-packed by vd_pack_* into the K-contiguous layouts the kernels read.
  */

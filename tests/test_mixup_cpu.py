@@ -100,6 +100,21 @@ def test_loader_worker_processes_and_mixup_switch():
             assert bt[1].shape == (4, P, 1) and bt[5].shape == (4, P, 4) and bt[6].shape[2] == 4
         frac = sum(int(((bt[1] > 0) & (bt[1] < 1)).any()) for bt in got)
         assert frac >= 1                                    # blended samples carry fractional objectness targets
+        # every sample draws its OWN lambda from beta(1.5, 1.5): a task that shipped the parent's bound np.random.beta
+        # pickled the parent's generator state with it, and every worker drew one and the same ratio for every sample
+        ratios = lambda batches: {round(float(v), 6) for bt in batches for v in np.unique(bt[1]) if 0.0 < v < 1.0}
+        r1 = ratios(got)
+        assert len(r1) >= 8, sorted(r1)
+        # a second epoch draws other ratios; the same seed in a fresh loader - with another worker count - repeats the
+        # first run bit for bit (per-sample generators seeded with (seed, rank, epoch, index))
+        got2 = list(ld)
+        assert ratios(got2) != r1
+        ld3 = Loader(ds, tfs, 4, train=True, shuffle=True, seed=3, interval=1, num_workers=3)
+        try:
+            again = list(ld3)
+        finally:
+            ld3.close()
+        assert len(again) == len(got) and all(np.array_equal(a, b) for x, y in zip(again, got) for a, b in zip(x, y))
         ds.set_mixup(None)                                  # the last --no_mixup_epochs epochs: travels with the tasks
         for bt in ld:
             assert set(np.unique(bt[1])) <= {0.0, 1.0}

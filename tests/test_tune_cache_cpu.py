@@ -57,7 +57,16 @@ def _worker(rank, world, port, path, q):
     from viddet_amd.model import TuneCache
     vd.init_from_env(backend="gloo")
     try:
+        # rank 1 has a table of its own (another node's disk, a stale copy): it must not be read - rank 0's table is the
+        # job's table, or rank 0 would enter agree()'s broadcast for ("pre", 1) alone
+        if rank == 1:
+            os.environ["VD_TUNE_CACHE"] = path + ".rank1"
+            json.dump({"library": TuneCache.library_id(), "entries": {"('pre', 1)": [1, 1], "('only1', 1)": 3}}, open(path + ".rank1", "w"))
+        else:
+            json.dump({"library": TuneCache.library_id(), "entries": {"('pre', 2)": [2, 2]}}, open(path, "w"))
+        vd.barrier()
         c = TuneCache()
+        assert ("pre", 1) not in c and ("only1", 1) not in c and ("pre", 2) in c and c[("pre", 2)] == (2, 2)
         mine = (64, 5) if rank == 0 else (16, 2)           # the ranks' timings disagree
         got = c.agree(mine)
         c[("k", 1)] = got
@@ -87,4 +96,4 @@ def test_ranks_adopt_rank0_choice(tmp_path):
     assert [r[1] for r in res] == [(64, 5), (64, 5)] and [r[2] for r in res] == [64, 64], res
     assert all(r[3] for r in res)
     doc = json.load(open(path))
-    assert doc["entries"] == {"('k', 1)": [64, 5], "('wgrad', 1)": 64}
+    assert doc["entries"] == {"('k', 1)": [64, 5], "('pre', 2)": [2, 2], "('wgrad', 1)": 64}

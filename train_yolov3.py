@@ -391,7 +391,12 @@ def main(argv=None):
     if FLAGS.trained_on.strip():
         net.reset_class(train_dataset.classes)
     train_data, val_data = get_dataloader(train_dataset, val_dataset, FLAGS.data_shape, FLAGS.batch_size, rank, world)
-    train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, start_epoch, FLAGS.num_samples, rank, world)
+    try:
+        train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, start_epoch, FLAGS.num_samples, rank, world)
+    finally:
+        for ld in (train_data, val_data):                # the loaders' worker pools (not left to __del__)
+            if ld is not None and hasattr(ld, "close"):
+                ld.close()
     return net
 
 

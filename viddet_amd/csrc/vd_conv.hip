@@ -1951,6 +1951,10 @@ int vd_conv_wgrad(const vd_wgrad_desc* d, void* ws, int64_t ws_bytes, void* stre
     VD_REQUIRE(d->ldd >= d->Co && d->ldd % 4 == 0, "vd_conv_wgrad: bad ldd");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_wgrad: in_scale/in_shift mismatch");
     VD_REQUIRE(!(d->flags & VD_STORE_BF16) || !d->in_scale, "vd_conv_wgrad: no in-load transform on bf16-stored operands");
+    // bf16-stored operands move as 16-byte loads of EIGHT channels: a group may not straddle a tap, a row end or Co
+    VD_REQUIRE(!(d->flags & VD_STORE_BF16) || (d->Ci % 8 == 0 && d->Co % 8 == 0 && d->ldd % 8 == 0 &&
+                                               ((uintptr_t)d->in | (uintptr_t)d->dout) % 16 == 0),
+               "vd_conv_wgrad: VD_STORE_BF16 needs Ci=%d, Co=%d, ldd=%d multiples of 8 and 16-byte aligned in / dout", d->Ci, d->Co, d->ldd);
     VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || d->Co < 64 || (d->amax_in && d->amax_dout && !d->in_scale),
                "vd_conv_wgrad: VD_MATH_F16X2 needs amax_in and amax_dout (and no in-load transform)");
     VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31) && (int64_t)d->N * d->Hi * d->Wi < (1ll << 31),

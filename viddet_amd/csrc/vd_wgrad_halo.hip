@@ -421,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_wgrad_halo(const vd_wgrad_desc 
     }
 }
 
+// (process-wide caches here and in launch_k: one device per process, include/viddet_hip.h "Conventions")
 const void* zero_page_wh() {
     static const void* zp = nullptr;
     if (!zp) {
@@ -466,7 +467,8 @@ WhCfg wh_config(const vd_wgrad_desc& d) {
         c.ring = wh_lds_bytes(bf, bm, bp, pow2) <= LDS ? pow2 : need;     // power of two (wrap = one and) where it fits
         c.p2 = (c.ring & (c.ring - 1)) == 0;
         c.lds = wh_lds_bytes(bf, bm, bp, c.ring);
-        c.ok = true;
+        // the position cursors carry over at most two images per step: a map too small for 64 positions retries 32
+        c.ok = bp / (d.Wi + 1) < 2 * (d.Hi + 1);
     }
     return c;
 }
@@ -523,8 +525,7 @@ bool vd_wgrad_halo_ok(const vd_wgrad_desc& d) {
         if (d.dz[t] != 0 || d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1) return false;
     if ((int64_t)d.N * (d.Hi + 1) * (d.Wi + 1) >= (1ll << 31) - (1 << 17)) return false;
     const WhCfg c = wh_config(d);
-    if (!c.ok || d.Co < c.bm || d.Ci % (c.nch * WH_CH) != 0) return false;          // (no half-empty co tile)
-    return c.bp / (d.Wi + 1) < 2 * (d.Hi + 1);             // the position cursors carry over at most two images per step
+    return c.ok && d.Co >= c.bm && d.Ci % (c.nch * WH_CH) == 0;          // (no half-empty co tile; the carry bound is wh_config's)
 }
 
 // split count: the fullest last round of 256 - VD_WGRAD_HALO_RESERVE one-per-CU workgroups, as wgrad_pick_splits

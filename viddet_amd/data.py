@@ -311,10 +311,10 @@ class Loader:
                  rank=0, world=1, interval=10, num_workers=0):
         self.ds, self.tf, self.bs, self.train = dataset, transform, batch_size, train
         # num_workers > 0: samples are read and transformed in that many worker processes (the reference's
-        # DataLoader(num_workers=...), train_yolov3.py:242-280), one batch ahead of the consumer.  Every worker re-seeds
-        # the transforms' random pair with (seed, rank, worker) - as with the reference's workers the augmentation draws
-        # are then per worker, not one global sequence; num_workers = 0 keeps the single deterministic sequence.
-        self.num_workers, self._seed, self._pool = max(0, int(num_workers)), seed, None
+        # DataLoader(num_workers=...), train_yolov3.py:242-280), one batch ahead of the consumer.  Every SAMPLE's draws
+        # are seeded with (seed, rank, epoch, sample index), so a run is reproducible whatever worker takes which sample;
+        # num_workers = 0 keeps the single sequential stream.
+        self.num_workers, self._seed, self._pool, self._epoch = max(0, int(num_workers)), seed, None, 0
         self.shuffle, self.last_batch, self._rng = shuffle, last_batch, np.random.default_rng(seed)
         self.rank, self.world = rank, world
         self.tfs = list(transform) if isinstance(transform, (list, tuple)) else None
@@ -360,27 +360,45 @@ class Loader:
         return [tf(*self.ds[int(j)], int(j)) for j in chunk]
 
     # ---- worker processes -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _mix_token(ds):
+        """What a task carries about the dataset's mix function (train_yolov3.py:571-581 switches it per epoch on the
+        parent's copy).  A draw of numpy's global generator (`np.random.beta`, ...) travels as its NAME: the bound method
+        itself would pickle the parent's generator state, and every worker would then draw the same lambda for every
+        sample.  Any other callable travels as it is (it must be picklable and carry its own randomness)."""
+        if not isinstance(ds, MixupDetection):
+            return None
+        f = ds._mixup
+        if f is None:
+            return ('none',)
+        owner = getattr(f, "__self__", None)
+        if isinstance(owner, np.random.RandomState) or owner is np.random:
+            return ('np.random', f.__name__, tuple(ds._mixup_args))
+        return ('callable', f, tuple(ds._mixup_args))
+
     def _iter_workers(self, idx):
-        """The same batches as the single-process loop, produced by the pool one batch ahead."""
+        """The same batches as the single-process loop, produced by the pool one batch ahead.  Every sample's random
+        draws come from generators seeded with (seed, rank, epoch, sample index) - `_sample_seed` - so the augmentation
+        of a sample does not depend on which worker happens to transform it: a fixed `seed` reproduces the run for any
+        num_workers > 0 (the single-process loop keeps its one sequential stream)."""
         if self._pool is None:
             import multiprocessing as mp
             # fresh interpreters (spawn), not forks of this process: it has the GPU open, its children must not inherit
             # that; viddet_amd.data imports NumPy only, so a worker starts in a fraction of a second
             ctx = mp.get_context("spawn")
-            counter = ctx.Value("i", 0)
             self._pool = ctx.Pool(self.num_workers, initializer=_worker_init,
-                                  initargs=(self.ds, self.tfs if self.tfs is not None else [self.tf], self.train,
-                                            self._seed * 1000003 + self.rank * 1009, counter))
+                                  initargs=(self.ds, self.tfs if self.tfs is not None else [self.tf], self.train))
+        epoch = self._epoch
+        self._epoch += 1
         pending = None
         for i in range(len(self)):
             chunk = idx[i * self.bs:(i + 1) * self.bs]
             if self.tfs is not None and i % self.interval == 0:
                 self.tf = self.tfs[int(self._choice.randint(len(self.tfs)))]
             ti = self.tfs.index(self.tf) if self.tfs is not None else 0
-            # the dataset's mix function travels with every task: train_yolov3.py:571-581 switches it per epoch on the
-            # parent's copy, the workers hold their own
-            mix = (self.ds._mixup, self.ds._mixup_args) if isinstance(self.ds, MixupDetection) else None
-            nxt = self._pool.map_async(_worker_sample, [(ti, int(j), mix) for j in chunk])
+            mix = self._mix_token(self.ds)
+            nxt = self._pool.map_async(_worker_sample, [(ti, int(j), mix, _sample_seed(self._seed, self.rank, epoch, int(j)))
+                                                        for j in chunk])
             if pending is not None:
                 yield self._collate(pending.get())
             pending = nxt
@@ -403,22 +421,30 @@ class Loader:
 _WORKER = {}
 
 
-def _worker_init(ds, tfs, train, seed, counter):
-    import random as _pyrandom
-    with counter.get_lock():
-        wid = counter.value
-        counter.value += 1
+def _sample_seed(seed, rank, epoch, j):
+    """32-bit seed of one sample's draws: a SeedSequence hash of (seed, rank, epoch, sample index)."""
+    return int(np.random.SeedSequence([int(seed) & 0xffffffff, int(rank), int(epoch), int(j)]).generate_state(1)[0])
+
+
+def _worker_init(ds, tfs, train):
     _WORKER.update(ds=ds, tfs=tfs, train=train)
-    np.random.seed((seed + wid) % (2 ** 32))             # the global modules (Rng() transforms draw from them)
-    _pyrandom.seed(seed + wid)
-    for t in tfs:                                        # private pairs: one sequence per worker
-        if getattr(t, "_rng", None) is not None:
-            t._rng = Rng.seeded((seed + wid) % (2 ** 32))
 
 
 def _worker_sample(task):
-    ti, j, mix = task
+    import random as _pyrandom
+    ti, j, mix, sseed = task
     tf, ds = _WORKER["tfs"][ti], _WORKER["ds"]
+    # this sample's generators: the global modules (Rng() transforms and MixupDetection draw from them) and the
+    # transform's private pair
+    np.random.seed(sseed)
+    _pyrandom.seed(sseed)
+    if getattr(tf, "_rng", None) is not None:
+        tf._rng = Rng.seeded(sseed)
     if mix is not None:
-        ds.set_mixup(mix[0], *mix[1])
+        if mix[0] == 'none':
+            ds.set_mixup(None)
+        elif mix[0] == 'np.random':
+            ds.set_mixup(getattr(np.random, mix[1]), *mix[2])      # THIS process's generator, seeded above
+        else:
+            ds.set_mixup(mix[1], *mix[2])
     return tf(*ds[j]) if _WORKER["train"] else tf(*ds[j], j)

@@ -124,7 +124,7 @@ class TuneCache(dict):
 
     def __init__(self):
         super().__init__()
-        self._loaded, self._dirty, self.tuned, self.hits = False, False, 0, 0
+        self._loaded, self._dirty, self.tuned, self.hits, self._synced_world = False, False, 0, 0, 1
 
     @staticmethod
     def library_id():
@@ -140,6 +140,10 @@ class TuneCache(dict):
                 h.update(open(f, "rb").read())
         else:
             h.update(open(L.LIB_PATH, "rb").read())
+        # library switches that change what a timed launch runs (the default keeps the hash of the sources alone)
+        for sw in ("VD_WGRAD_RESERVE",):
+            if os.environ.get(sw):
+                h.update(("%s=%s" % (sw, os.environ[sw])).encode())
         return h.hexdigest()[:12]
 
     def path(self):
@@ -151,27 +155,64 @@ class TuneCache(dict):
             return p
         return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune", "gfx950_%s.json" % self.library_id())
 
-    def load(self):
+    @staticmethod
+    def _world():
+        if not torch.distributed.is_available() or not torch.distributed.is_initialized():
+            return 1
+        return torch.distributed.get_world_size()
+
+    @staticmethod
+    def device_arch():
+        """gcnArchName of the current device without its feature suffixes ('gfx950'), None without a GPU"""
+        if not torch.cuda.is_available():
+            return None
+        return str(torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName).split(":")[0]
+
+    def _read_file(self):
         import ast
         import json
         import os
-        self._loaded = True
+        out = {}
         p = self.path()
         if p is None or not os.path.exists(p):
-            return
+            return out
         try:
             doc = json.load(open(p))
             if doc.get("library") not in (None, self.library_id()):
-                return                                   # timed on other kernels
+                return out                               # timed on other kernels
+            arch = self.device_arch()
+            if arch is not None and doc.get("device") not in (None, arch):
+                return out                               # timed on another device
             for k, v in doc.get("entries", {}).items():
-                key = ast.literal_eval(k)
-                if not dict.__contains__(self, key):
-                    dict.__setitem__(self, key, tuple(v) if isinstance(v, list) else v)
+                out[ast.literal_eval(k)] = tuple(v) if isinstance(v, list) else v
         except (OSError, ValueError, SyntaxError) as e:   # an unreadable table is a cold start, not an error
             print("viddet_amd: ignoring tuning table %s (%s)" % (p, e), flush=True)
+            return {}
+        return out
+
+    def load(self):
+        """Read the table.  Under torch.distributed ONLY rank 0 reads the file and every rank adopts its entries (one
+        broadcast at first use): ranks that read their own copies - another node's file system, another VD_TUNE_CACHE,
+        a file rank 0 has rewritten since - would disagree on hit or miss, and the ranks that miss would enter `agree`'s
+        broadcast alone.  After this every lookup gives the same answer on every rank, so `agree` is entered by all or none."""
+        import os
+        self._loaded = True
+        world = self._world()
+        self._synced_world = world
+        if world > 1 and os.environ.get("VD_TUNE_AGREE", "1") != "0":
+            box = [self._read_file() if torch.distributed.get_rank() == 0 else None]
+            torch.distributed.broadcast_object_list(box, src=0)
+            dict.clear(self)                              # rank 0's table, nothing else
+            entries = box[0]
+        else:
+            entries = self._read_file()
+        for key, v in entries.items():
+            if not dict.__contains__(self, key):
+                dict.__setitem__(self, key, v)
 
     def __contains__(self, key):
-        if not self._loaded:
+        # (a process group that came up after the first lookup: sync once more - every rank is in the same position)
+        if not self._loaded or self._synced_world != self._world():
             self.load()
         hit = dict.__contains__(self, key)
         self.hits += int(hit)
@@ -209,7 +250,7 @@ class TuneCache(dict):
             return
         try:
             os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
-            doc = {"library": self.library_id(), "device": "gfx950",
+            doc = {"library": self.library_id(), "device": self.device_arch() or "gfx950",
                    "entries": {repr(k): (list(v) if isinstance(v, tuple) else v) for k, v in sorted(self.items(), key=lambda kv: repr(kv[0]))}}
             tmp = "%s.%d.tmp" % (p, os.getpid())
             with open(tmp, "w") as f:

@@ -180,6 +180,8 @@ def conv_wgrad(x, dout, dwp, ws, *, k, stride, pad, Co, kd=1, pad_d=0, kfr=1, sp
         d.flags = (MATH_BF16 if split == 'bf16' else MATH_SPLIT) if split else 0
     if x.dtype == torch.bfloat16:               # bf16-storage training: both operands bf16, the gradient fp32
         assert dout.dtype == torch.bfloat16 and dwp.dtype == torch.float32
+        assert Ci % 8 == 0 and Co % 8 == 0 and ldd % 8 == 0 and x.data_ptr() % 16 == 0 and dout.data_ptr() % 16 == 0, \
+            "bf16-stored operands: Ci, Co and the gradient pitch multiples of 8, 16-byte aligned tensors"
         d.flags = L.STORE_BF16 | MATH_BF16 | (L.WGRAD_HALO if split == 'halo' else 0)
     lib = _lib()
     need = lib.vd_conv_wgrad_ws_bytes(C.byref(d))
