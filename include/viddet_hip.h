@@ -71,6 +71,16 @@ extern "C" {
  * activation rows ONCE per pixel in a sliding LDS ring that the nine taps read at shifted rows (vd_wgrad_halo.hip), instead
  * of gathering the activation tile once per tap.  Same arithmetic, slabs and reduction; other geometries ignore the flag. */
 #define VD_WGRAD_HALO    512
+/* VD_CONV_STREAMK (vd_conv_desc.flags, with VD_MATH_F16X2): run the launch as a PERSISTENT stream-K grid - one workgroup
+ * per CU slot, each owning an equal contiguous run of (tile, K-unit) units instead of whole tiles, so the launch ends
+ * together on every CU whatever the tile count (vd_conv_sk.hip).  A tile cut by a run boundary is finished by the next
+ * workgroup FROM the first one's accumulators (handed over through sk_ws), i.e. the same MFMA chain in the same order:
+ * results are bit-identical to the launch without the flag.  Needs vd_conv_desc.sk_ws / sk_ws_bytes; where the form does
+ * not apply (too few tiles, workspace too small, another arithmetic) the flag is ignored.  vd_conv_igemm_streamk(d) tells. */
+#define VD_CONV_STREAMK  1024
+#define VD_SK_MAX_WG        2048     /* seam counters per workspace (the last one counts the polls that gave up: diagnostics) */
+#define VD_SK_HEADER_BYTES  16384    /* [VD_SK_MAX_WG] u32 hand-off counters + [VD_SK_MAX_WG] u32 consumed counts */
+#define VD_SK_TIMEOUT_TICKS 4000     /* bound of the hand-off poll in 10 ns ticks, after which the consumer recomputes */
 #define VD_AMAX_SLOTS    32
 #define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
 #define VD_AMAX_FLOATS   (VD_AMAX_SLOTS * VD_AMAX_STRIDE)   /* floats per tensor */
@@ -82,7 +92,7 @@ int vd_version(void);
  * header would have passed its stream handle as amax_out).  A binding checks vd_abi_version() == VD_ABI_VERSION and
  * vd_sizeof_desc(i) == sizeof(its mirror of the descriptor) at load, before the first compute call: viddet_amd/lib.py
  * does, INTEGRATION.md shows it.  i: 0 = vd_conv_desc, 1 = vd_wgrad_desc, 2 = vd_head_desc; unknown i -> -1. */
-#define VD_ABI_VERSION 4
+#define VD_ABI_VERSION 5
 int vd_abi_version(void);
 int64_t vd_sizeof_desc(int which);
 
@@ -145,9 +155,19 @@ typedef struct {
     const float* amax_w;
     /* optional, any arithmetic: the epilogue publishes the max-abs of what it stores (zeroed by the caller) */
     float*  amax_out;
+    /* VD_CONV_STREAMK: hand-off workspace, vd_conv_igemm_streamk_ws_bytes() bytes.  The caller zeroes its first
+     * VD_SK_HEADER_BYTES ONCE, when it allocates it (the counters are monotonic across launches), and never shares one
+     * workspace between launches that may run at the same time (one per stream). */
+    void*   sk_ws;
+    int64_t sk_ws_bytes;
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);
+/* 1 when vd_conv_igemm(d) would run as a persistent stream-K grid (flag set, arithmetic / tile / tile count it serves and
+ * a large enough workspace), else 0: for host autotuners and tests. */
+int vd_conv_igemm_streamk(const vd_conv_desc* d);
+/* bytes of a stream-K workspace that serves every launch shape (header + one fp32 accumulator tile per CU slot) */
+int64_t vd_conv_igemm_streamk_ws_bytes(void);
 /* number of M tiles (rows of stats_part) the launch described by d will use */
 int vd_conv_igemm_mtiles(const vd_conv_desc* d);
 

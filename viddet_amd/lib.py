@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VD_LIB: developer override for A/B-testing a differently built kernel library (tools/ only)
 LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hip.so")
 
-ABI_VERSION = 4          # include/viddet_hip.h VD_ABI_VERSION
+ABI_VERSION = 5          # include/viddet_hip.h VD_ABI_VERSION
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
@@ -19,6 +19,8 @@ MATH_F16X2 = 64        # two-way fp16 operand split with per-tensor power-of-two
 MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-staged one (A/B timing)
 STORE_BF16 = 256       # vd_wgrad_desc.flags: `in` / `dout` are bf16 tensors (bf16-storage training)
 WGRAD_HALO = 512       # vd_wgrad_desc.flags: halo-ring kernel for 3x3 / stride-1 weight gradients (vd_wgrad_halo.hip)
+CONV_STREAMK = 1024    # vd_conv_desc.flags: persistent stream-K grid (vd_conv_sk.hip); bit-identical results
+SK_HEADER_BYTES = 16384
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 
@@ -40,6 +42,7 @@ class ConvDesc(C.Structure):
         ("bs_z", _fp), ("bs_scale", _fp), ("bs_shift", _fp), ("bs_mean", _fp), ("bs_invstd", _fp), ("bs_part", _fp),
         ("bs_slope", C.c_float),
         ("amax_in", _fp), ("amax_w", _fp), ("amax_out", _fp),
+        ("sk_ws", _fp), ("sk_ws_bytes", C.c_int64),
     ]
 
 
@@ -73,6 +76,8 @@ SIGNATURES = {
     "vd_sizeof_desc": (_i64, [_i]),
     "vd_conv_igemm": (_i, [C.POINTER(ConvDesc), _p]),
     "vd_conv_igemm_mtiles": (_i, [C.POINTER(ConvDesc)]),
+    "vd_conv_igemm_streamk": (_i, [C.POINTER(ConvDesc)]),
+    "vd_conv_igemm_streamk_ws_bytes": (_i64, []),
     "vd_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _i, _p]),
     "vd_conv_igemm_bf16_mtiles": (_i, [C.POINTER(ConvDesc)]),
     "vd_pack_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

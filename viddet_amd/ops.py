@@ -77,8 +77,10 @@ def _set_taps(d, taps):
 def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo,
                out_stride=1, out_oy=0, out_ox=0, scale=None, shift=None, residual=None, ldr=0,
                leaky=False, slope=0.1, kfr=1, in_scale=None, in_shift=None, in_slope=0.1, tile=0, split=False,
-               amax_in=None, amax_w=None, amax_out=None):
-    """split: False = fp32 MFMA; True / 'split' = exact 3-plane bf16 split; 'bf16' = one plane (bf16-rounded operands);
+               amax_in=None, amax_w=None, amax_out=None, streamk_ws=None, desc_out=None):
+    """streamk_ws: a workspace from streamk_workspace() - the launch runs as a persistent stream-K grid where that form
+    applies (VD_CONV_STREAMK; bit-identical results).
+    split: False = fp32 MFMA; True / 'split' = exact 3-plane bf16 split; 'bf16' = one plane (bf16-rounded operands);
     'f16x2' = two fp16 planes with per-tensor scales - the max-abs slots of x and wp (amax_in / amax_w, see amax())
     are computed here when not given."""
     d = ConvDesc()
@@ -107,14 +109,28 @@ def conv_igemm(x, wp, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co
     elif split:
         flags |= MATH_BF16 if split == 'bf16' else MATH_SPLIT
     d.amax_out = ptr(amax_out)
+    if streamk_ws is not None:
+        flags |= L.CONV_STREAMK
+        d.sk_ws, d.sk_ws_bytes = ptr(streamk_ws), streamk_ws.numel() * streamk_ws.element_size()
     d.flags, d.slope = flags, slope
     d.in_scale, d.in_shift, d.in_slope = ptr(in_scale), ptr(in_shift), in_slope
+    if desc_out is not None:
+        desc_out.append(d)
     check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm")
+
+
+def streamk_workspace(device=None):
+    """A stream-K hand-off workspace (vd_conv_desc.sk_ws): its counter header zeroed once, here; one per stream that may
+    run such launches at the same time."""
+    n = int(_lib().vd_conv_igemm_streamk_ws_bytes())
+    ws = torch.empty(n, dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+    ws[:L.SK_HEADER_BYTES].zero_()
+    return ws
 
 
 def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None, residual=None,
              leaky=False, slope=0.1, kd=1, pad_d=0, kfr=1, tile=0, split=False, amax_in=None, amax_w=None,
-             amax_out=None, in_scale=None, in_shift=None, in_slope=0.1):
+             amax_out=None, in_scale=None, in_shift=None, in_slope=0.1, streamk_ws=None, desc_out=None):
     """Forward conv on NHWC x [N,Hi,Wi,Ci] with fwd-packed weights wp [>=Co][T*Ci] -> out [N,Ho,Wo,ldo].
     in_scale / in_shift: per-input-channel transform leaky(x * s + b) applied in the operand gather (the padding stays zero)."""
     N, Hi, Wi, Ci = x.shape
@@ -124,7 +140,8 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
     conv_igemm(x, wp, out, N=N, Hi=Hi, Wi=Wi, Ci=Ci, Hg=Ho, Wg=Wo, in_stride=stride,
                taps=fwd_taps(k, pad, kd, pad_d), Ho=Ho, Wo=Wo, Co=Co, ldo=ldo, scale=scale, shift=shift,
                residual=residual, ldr=ldo, leaky=leaky, slope=slope, kfr=kfr, tile=tile, split=split,
-               amax_in=amax_in, amax_w=amax_w, amax_out=amax_out, in_scale=in_scale, in_shift=in_shift, in_slope=in_slope)
+               amax_in=amax_in, amax_w=amax_w, amax_out=amax_out, in_scale=in_scale, in_shift=in_shift, in_slope=in_slope,
+               streamk_ws=streamk_ws, desc_out=desc_out)
     return Ho, Wo
 
 
