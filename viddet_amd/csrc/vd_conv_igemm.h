@@ -195,7 +195,7 @@ struct RowInfo {
 // one-workgroup-per-tile kernel's (nothing is summed across the seam).  The hand-off is needed a whole run after it was
 // published; a bounded poll that gives up recomputes the prefix itself, so no dispatch order can hang the grid.
 template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3, bool HALO = false, bool SK = false>
-__global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && WM * WN == 4) ? 2 : 1))) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w, const int sk_lds_flag) {
+__global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && WM * WN == 4) ? 2 : 1))) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w, const int sk_lds_flag, const int sk_timeout) {
     static_assert(NPL == 3 || ((NPL == 1 || NPL == 2) && SP), "planes");
     static_assert(!SK || (NPL == 2 && VD_KORDER && !VD_KROT && !XF), "stream-K: the fp16-split tiles, taps-innermost K order");
     static_assert(NPL != 2 || !XF, "the fp16 split needs the max-abs of the operand it splits: no in-load transform");
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
                 int ok = 0;
                 for (;;) {
                     const unsigned c = __hip_atomic_load(cnt + sk_me - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int)(c - target) >= 0) { ok = 1; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)VD_SK_TIMEOUT_TICKS) break;
+                    if ((int)(c - target) >= 0 && sk_timeout > 0) { ok = 1; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)sk_timeout) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
                 __hip_atomic_store(seen + sk_me, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1414,7 +1414,9 @@ int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
     }
     const float* zp = zero_page();
     const int64_t zd_in = zp - d.in, zd_w = zp - d.wp;      // element deltas (all pointers are float-aligned)
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w, sk_flag_off);
+    // (developer / test switch VD_SK_TIMEOUT_TICKS: 0 makes every consumer give up at once and recompute its prefix)
+    static const int sk_timeout = getenv("VD_SK_TIMEOUT_TICKS") ? atoi(getenv("VD_SK_TIMEOUT_TICKS")) : VD_SK_TIMEOUT_TICKS;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w, sk_flag_off, sk_timeout);
     return 0;
 }
 

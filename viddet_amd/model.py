@@ -92,7 +92,8 @@ class Program:
                 if fname in ("vd_conv_igemm", "vd_conv_wgrad"):     # which product arithmetic this record runs in
                     d = args[0]._obj
                     meta = dict(meta or {}, split=bool(d.flags & L.MATH_SPLIT), bf16=bool(d.flags & L.MATH_BF16),
-                                f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)))
+                                f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)),
+                                streamk=bool(fname == "vd_conv_igemm" and L.load().vd_conv_igemm_streamk(args[0])))
                     if fname == "vd_conv_wgrad":                # the halo-ring kernel (vd_wgrad_halo.hip) or the generic one
                         meta["wgrad_halo"] = bool(L.load().vd_conv_wgrad_uses_halo(args[0]))
                     if fname == "vd_conv_igemm" and meta.get("bytes"):
@@ -290,7 +291,25 @@ _MATH_OVERRIDE = [None]
 # 'split2' = two-way fp16 operand split with per-tensor power-of-two scales (VD_MATH_F16X2: three MFMAs per product block
 # instead of six, fp32-accurate); 'auto' times native, split and split2 per launch record
 _MATH_MODES = ("native", "split", "split2", "auto", "bf16")
-_ALL_MATH = L.MATH_SPLIT | L.MATH_BF16 | L.MATH_F16X2 | L.MATH_NOHALO
+_ALL_MATH = L.MATH_SPLIT | L.MATH_BF16 | L.MATH_F16X2 | L.MATH_NOHALO | L.CONV_STREAMK
+
+
+def _streamk_on():
+    """VD_STREAMK=0: never the persistent stream-K form of k_conv_igemm (read when a plan is built).  The form changes how a
+    launch is cut into workgroups, not one bit of what it computes (vd_conv_sk.hip), so this is a speed switch only."""
+    return __import__('os').environ.get('VD_STREAMK', '1') != '0'
+
+
+def _streamk_applies(d, fl, tile):
+    """would vd_conv_igemm run this record as a stream-K grid with arithmetic `fl` and tile `tile`?"""
+    if not (d.sk_ws and (fl & L.MATH_F16X2)):
+        return False
+    keep = (d.flags, d.tile)
+    d.flags, d.tile = (d.flags & ~_ALL_MATH) | fl | L.CONV_STREAMK, tile
+    try:
+        return bool(L.load().vd_conv_igemm_streamk(C.byref(d)))
+    finally:
+        d.flags, d.tile = keep
 
 
 def set_conv_math(mode):
@@ -344,6 +363,8 @@ def autotune_desc(d, reps=3):
     if os.environ.get("VD_AUTOTUNE", "1") == "0":
         f16 = L.MATH_F16X2 if (d.amax_in and d.amax_w and not d.in_scale) else L.MATH_SPLIT
         d.flags = base | {"split": L.MATH_SPLIT, "split2": f16, "bf16": L.MATH_BF16}.get(math, 0)
+        if d.flags & L.MATH_F16X2 and d.T >= 9 and d.sk_ws and _streamk_on():
+            d.flags |= L.CONV_STREAMK                     # (the library ignores it where the form does not apply)
         if os.environ.get("VD_TILE_ALT", "0") == "1":
             # a second, equally deterministic tile set (the last candidate of the launch record's list instead of the
             # kernel's heuristic tile): other M-tile heights, hence other groupings of the BatchNorm partial sums and
@@ -377,6 +398,10 @@ def autotune_desc(d, reps=3):
                 print("igemm tune %s math %d tile %d: %.4f ms (%d launches)" % (key[1:11], fl, c, t, n), flush=True)
             return t
         ranked = sorted((time_of(fl, c, reps), (fl, c)) for fl, c in cands)
+        # the persistent stream-K form of the three fastest tiles (same bits, another cut of the launch into workgroups)
+        if _streamk_on():
+            sk = [(fl | L.CONV_STREAMK, c) for _, (fl, c) in ranked[:3] if _streamk_applies(d, fl, c)]
+            ranked = sorted(ranked + [(time_of(fl, c, reps), (fl, c)) for fl, c in sk])
         best = ranked[0][1]
         # candidates within 4 % of the fastest are re-timed with more launches: the first pass is 3 launches each, and
         # launch-to-launch noise under the power limit is of that order
@@ -829,6 +854,7 @@ class YOLOV3(object):
         self._training = False
         self._recording = False
         self._programs = {}
+        self._sk_ws = {}           # stream-K hand-off workspaces by stream index (_set_streamk)
         self._fold_dirty = True
         self._stats_version = 1          # bumped whenever the BatchNorm running statistics move
         self._weights_version = 1        # bumped whenever the weights move; each training plan packs its own data-gradient
@@ -1170,9 +1196,20 @@ class YOLOV3(object):
             d.residual = residual.data_ptr()
         d.flags, d.slope = flags, LEAKY_SLOPE
         d.amax_in, d.amax_w = bufs['amax:' + n.src].data_ptr(), n.wamax.data_ptr()
+        self._set_streamk(d, 0)
         if amax_out:                                   # inference: the epilogue publishes the max-abs of what it writes
             d.amax_out = bufs['amax:' + n.dst].data_ptr()
         return d
+
+    def _set_streamk(self, d, stream_idx):
+        """give a conv record the stream-K hand-off workspace of the stream it runs on (0 = the program's main stream,
+        1.. = the parity streams of a stride-2 data gradient): launches that may overlap never share one"""
+        if not _streamk_on():
+            return
+        ws = self._sk_ws.get(stream_idx)
+        if ws is None:
+            ws = self._sk_ws[stream_idx] = ops.streamk_workspace(self.device)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
 
     def _add_sel_add_fwd(self, prog, n, bufs, B):
         """Forward launches of a SelNode / AddNode (the same in inference and training)."""
@@ -2002,6 +2039,7 @@ class YOLOV3(object):
                 d.ldo = d.ldr = n.cin
                 d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
                 d.amax_in, d.amax_w = amx('dz:' + n.name), n.wamax.data_ptr()
+                self._set_streamk(d, pi if (par is not None) else 0)
                 if acc:
                     d.residual = res_src.data_ptr()
                 seg.hold(d, wpk)
