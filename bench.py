@@ -329,6 +329,12 @@ def main():
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launches": ig[2], "avg_launch_ms": round(ig[1] / ig[2], 4),
                 "algorithmic_gflop_per_launch": round(ig[0] / ig[2] / 1e9, 3)}
+        # launches the plan runs as persistent stream-K grids (VD_CONV_STREAMK: bit-identical results, another cut of the
+        # launch into workgroups; the autotuner takes the form per launch record where it is faster)
+        sk_recs = [(m, e0.elapsed_time(e1)) for f_, m, e0, e1 in recs if f_ == "vd_conv_igemm" and m.get("streamk")]
+        roof["streamk"] = {"launches": len(sk_recs), "ms": round(sum(t for _, t in sk_recs), 3),
+                           "tflops": round(sum(m["flops"] for m, _ in sk_recs) / max(1e-9, sum(t for _, t in sk_recs)) / 1e9, 2) if sk_recs else None,
+                           "switch": "VD_STREAMK=%s" % os.environ.get("VD_STREAMK", "1")}
         if math is not None:
             roof["by_math"] = math
             # not part of `frac`: what a bare f16-MFMA K loop of the kernel's shape sustains on this chip with random
@@ -338,7 +344,8 @@ def main():
                     "f16_mfma_tflops_random_operands": 1470.0, "f16_mfma_tflops_zero_operands": 2250.0,
                     "fp32_equivalent_tflops": round(1470.0 / 3, 1),
                     "f16x2_launches_frac_of_it": round(math["f16x2"]["tflops"] / (1470.0 / 3), 4),
-                    "source": "profiles/r02_mfma_ceiling.txt (tools/mfma_ceiling.hip)"}
+                    "source": "profiles/r02_mfma_ceiling.txt (tools/mfma_ceiling.hip): a round-2 measurement on another box, "
+                              "copied here as a yardstick - not measured in this run"}
             roof["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
         roof["algorithmic_mb_per_launch"] = round(sum(m["bytes"] for f_, m, _, _ in recs if f_ == "vd_conv_igemm") / ig[2] / 1e6, 1)
         # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this very
@@ -346,10 +353,14 @@ def main():
         try:
             if train and B == 64 and S == 416 and C == 80:
                 import glob
-                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_b64_416_pmc_traffic.json")))[-1]))
+                pmf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_b64_416_pmc_traffic.json")))[-1]
+                pm = json.load(open(pmf))
                 roof["traffic"] = round(pm["k_conv_igemm"]["hbm_mb_corrected"], 1)
                 roof["traffic_unit"] = ("MB per launch leaving the L2s (2 x FETCH_SIZE + WRITE_SIZE over the final step's launches; "
                                         "MALL hits count as fetches, so this bounds HBM bytes from above)")
+                # NOT measured in this run: PMC passes need rocprofv3 around the process (tools/pmc_traffic.py); the number
+                # is read from the newest committed pass of this very command
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of `python bench.py`, committed; not measured live)" % os.path.basename(pmf)
         except Exception:
             pass
         for k, v in agg.items():
@@ -436,6 +447,26 @@ def main():
         except Exception as e:  # noqa: BLE001  (a diagnostic sub-line must never take the headline down)
             detect = {"error": repr(e)[:200]}
 
+    # ---- north_star's second training size ("synthetic 416x416 and 608x608"): fp32, 80 classes, 608x608, batch 32 - the same
+    # script as a child process (its own plans), frames/s and the dominant kernel's rate embedded here
+    train_608 = None
+    if train and rank == 0 and world == 1 and not force_dist and not a.no_detect and K == 1 and a.dtype == "f32" \
+            and a.batch == 0 and a.size == 0:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--size", "608", "--batch", "32", "--steps", "10", "--warmup", "3",
+                                "--no-cpu-baseline", "--no-native", "--no-detect"], capture_output=True, text=True, timeout=900)
+            tj = json.loads(r.stdout.strip().splitlines()[-1])
+            train_608 = {"metric": tj["metric"], "value": tj["value"], "unit": tj["unit"], "ms_per_step": tj["ms_per_step"],
+                         "dtype": tj["dtype"], "config": tj["config"]["workload"],
+                         "model_tflops": round(tj["value"] * 421.4 / 1e3, 2),       # 421.4 GFLOP per frame at 608 / C = 80
+                         "roofline": {k: tj["roofline"][k] for k in ("achieved", "peak", "frac", "launches", "avg_launch_ms", "streamk")
+                                      if k in tj["roofline"]},
+                         "kernels": {k: tj["kernels"][k] for k in ("igemm_3x3s1_fwd", "vd_conv_wgrad", "bn_apply_leaky") if k in tj["kernels"]}}
+            train_608["kernels"].get("vd_conv_wgrad", {}).pop("by_kernel", None)
+        except Exception as e:  # noqa: BLE001
+            train_608 = {"error": repr(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.mode, S, C)
@@ -478,6 +509,8 @@ def main():
         }
         if detect is not None:
             out["detect"] = detect
+        if train_608 is not None:
+            out["train_608"] = train_608
         if gflop:
             out["model_tflops"] = round(fps * gflop / 1e3, 2)
         print(json.dumps(out))

@@ -59,9 +59,10 @@ def test_inference_matches_oracle(cfg):
     assert np.array_equal(ids.cpu().numpy(), ids_r)
     assert maxdiff(sc.cpu().numpy(), sc_r) < 1e-3
     # boxes: fp32 round-off of the 75-layer stack vs the fp64 oracle is ~1e-5 relative (measured 1.05e-3 px on
-    # +-100 px boxes), so the pixel tolerance is 5e-3; in detect()'s normalised units (detect_yolo3.py:257,
+    # +-100 px boxes of the 608x608 frame), so the pixel tolerance is 2e-3 (twice the measured worst case: a 2x
+    # regression of any conv kernel's error fails here); in detect()'s normalised units (detect_yolo3.py:257,
     # boxes / W) the north_star 1e-3 bound is met with a 10x margin
-    assert maxdiff(bx.cpu().numpy(), bx_r) < 5e-3
+    assert maxdiff(bx.cpu().numpy(), bx_r) < 2e-3
     assert maxdiff(bx.cpu().numpy() / size, bx_r / size) < 1e-4
     assert int((ids_r >= 0).sum()) > 0, "fixture produced no detections"
 
@@ -122,7 +123,8 @@ def test_training_step_matches_oracle(cfg):
         got = net.collect_params()[k].grad().cpu().numpy()
         scale = max(1e-3, float(np.abs(gref).max()))
         errs.append((maxdiff(got, gref) / scale, k, scale))
-    bad = [e for e in errs if e[0] >= 5e-3]
+    # (measured <= 5e-5 of a tensor's max on both fixtures: the bound is 10x that)
+    bad = [e for e in errs if e[0] >= 5e-4]
     print("\n".join("%-45s rel_err %.3e  scale %.3e" % (k, e, sc) for e, k, sc in errs))
     assert not bad, "gradient mismatch: %s" % bad[:8]
     # SGD-momentum step on top (wd on everything, rescale 1/batch)
@@ -384,7 +386,7 @@ def test_bench_two_ranks_launched_the_drivers_way():
 def test_fp16_split_arithmetic_matches_oracle(cfg):
     """set_conv_math('split2') (VD_MATH_F16X2: two fp16 pieces per operand, per-tensor power-of-two scales from the
     producers' max-abs, three MFMAs per product block): the SAME tolerances as the fp32 arithmetics - heads 1e-3, identical
-    post-NMS rows, losses 2e-3, every one of the 222 gradients 5e-3 of its tensor's max - on the small fixture and on one
+    post-NMS rows, losses 2e-3, every one of the 222 gradients 5e-4 of its tensor's max - on the small fixture and on one
     full 416x416 frame; and the launches really ran in it."""
     from viddet_amd import model as M
     from viddet_amd import lib as L
@@ -405,8 +407,8 @@ def test_fp16_split_arithmetic_matches_oracle(cfg):
             assert maxdiff(bufs[hname].cpu().numpy()[..., :3 * (5 + c)], np.moveaxis(heads_r[s_], 1, -1)) < 1e-3, s_
         perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
         assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3
-        # boxes: 5e-3 px, or 2e-5 of the coordinate for the exp()-blown boxes of this random-init fixture (+-1700 px)
-        assert np.all(np.abs(take_ranks(bx, perm) - bx_r) <= 5e-3 + 2e-5 * np.abs(bx_r))
+        # boxes: 2e-3 px, or 2e-5 of the coordinate for the exp()-blown boxes of this random-init fixture (+-1700 px)
+        assert np.all(np.abs(take_ranks(bx, perm) - bx_r) <= 2e-3 + 2e-5 * np.abs(bx_r))
         used = [bool(a[0]._obj.flags & L.MATH_F16X2) for (fn_, _, a) in net._programs[('infer', b, size, size)][0].recs
                 if fn_ == 'vd_conv_igemm']
         assert sum(used) >= 70, sum(used)
@@ -428,7 +430,7 @@ def test_fp16_split_arithmetic_matches_oracle(cfg):
             got = net.collect_params()[k].grad().cpu().numpy()
             e = maxdiff(got, gref) / max(1e-3, float(np.abs(gref).max()))
             worst = max(worst, e)
-            assert e < 5e-3, (k, e)
+            assert e < 5e-4, (k, e)
         print("fp16-split arithmetic: worst gradient error / tensor max = %.2e" % worst)
         for k, v in onet.new_running.items():
             assert maxdiff(net.collect_params()[k].data().cpu().numpy(), v) < 1e-4, k

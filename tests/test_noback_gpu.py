@@ -46,7 +46,7 @@ def test_extract_features_and_noback_inference():
     from tests.util import assert_rows_match, take_ranks
     perm = assert_rows_match(nb.last_rows.cpu().numpy(), rows_r, sc_r)
     assert np.array_equal(take_ranks(ids, perm), ids_r)
-    assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 5e-3
+    assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 2e-3
 
 
 def test_noback_call_protocol_errors():
@@ -82,7 +82,7 @@ def test_noback_training_step_matches_oracle():
     for k, gref in G.items():
         got = nb.collect_params()[k].grad().cpu().numpy()
         scale = max(1e-3, float(np.abs(gref).max()))
-        assert maxdiff(got, gref) / scale < 5e-3, k
+        assert maxdiff(got, gref) / scale < 5e-4, k
     for k, v in onet.new_running.items():
         assert maxdiff(nb.collect_params()[k].data().cpu().numpy(), v) < 1e-4, k
 

@@ -53,7 +53,7 @@ def test_temporal_inference_and_training(cfg):
         assert maxdiff(got, np.moveaxis(heads_r[s], 1, -1)) < 1e-3, "head %d" % s
     from tests.util import assert_rows_match, take_ranks
     perm = assert_rows_match(net.last_rows.cpu().numpy(), rows_r, sc_r)
-    assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 5e-3
+    assert maxdiff(take_ranks(sc, perm), sc_r) < 1e-3 and maxdiff(take_ranks(bx, perm), bx_r) < 2e-3
     # training step (labels belong to the window's centre frame: one gt set per window)
     gt = np.array([[[5., 8., 40., 50.], [-1, -1, -1, -1]], [[10., 12., 30., 28.], [20., 5., 60., 62.]]])
     gid = np.array([[[1.], [-1.]], [[0.], [2.]]])
@@ -113,7 +113,7 @@ def test_temporal_inference_and_training(cfg):
         scale = max(1e-3, float(np.abs(gref).max()))
         err = maxdiff(got, gref) / scale
         table.append("%-48s %.3e %.3e" % (k, err, scale))
-        if err >= 5e-3:
+        if err >= 5e-4:
             bad.append((k, err))
     print("\n".join(table))
     assert not bad, bad[:6]
