@@ -326,8 +326,12 @@ def test_data_parallel_two_ranks_equal_one_process():
     # duplicate shards: bit-identical step; real shards: the update agrees as a whole; then the BASELINE configs[3] family -
     # k = 3 windows with the SyncBN scope the reference's --syncbn reaches (stem + stride-2 convs), duplicate shards; and
     # three consecutive steps (momentum, the repacked weight layouts and max-abs slots after each update), bit-identical
+    # ... and bf16-storage training (BASELINE configs[4]'s mode: 8 GPUs, bf16) under the same SyncBN('all') + bucketed
+    # all-reduce: duplicate shards bit-identical over two steps, real shards within the bf16 tolerance
     for extra in (dict(VD_DP_DUP="1"), dict(), dict(VD_DP_DUP="1", VD_DP_K="3", VD_DP_SCOPE="reference"),
-                  dict(VD_DP_K="3"), dict(VD_DP_DUP="1", VD_DP_STEPS="3")):
+                  dict(VD_DP_K="3"), dict(VD_DP_DUP="1", VD_DP_STEPS="3"),
+                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_STEPS="2"), dict(VD_DP_STORAGE="bf16"),
+                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_SCOPE="reference")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
                            text=True, timeout=600, env=dict(base, **extra))
         assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (extra, r.stdout[-800:], r.stderr[-1500:])

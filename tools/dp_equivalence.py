@@ -22,6 +22,7 @@ os.environ.setdefault("VD_AUTOTUNE", "0")
 C, SIZE, PER_RANK = 4, 64, 2
 K = int(os.environ.get("VD_DP_K", "1"))                 # frames per window: 3 = the BASELINE configs[3] family (YOLOV3T, late max join)
 SCOPE = os.environ.get("VD_DP_SCOPE", "all")            # SyncBN scope: 'all', or 'reference' = the six layers --syncbn reaches
+STORAGE = os.environ.get("VD_DP_STORAGE", "fp32")      # 'bf16' = bf16-storage training (net.set_storage('bf16'), BASELINE configs[4]'s mode)
 STEPS = int(os.environ.get("VD_DP_STEPS", "1"))         # optimiser steps on the same batch (> 1: the repacks after a step, under DP)
 
 
@@ -52,6 +53,8 @@ def build(syncbn):
                           norm_kwargs={"scope": SCOPE} if syncbn else None,
                           **(dict(k=K, k_join_type="max", k_join_pos="late") if K > 1 else {}))
     net.initialize(init="he", seed=3, obj_bias=-1.0)
+    if STORAGE == "bf16":
+        net.set_storage("bf16")
     return net
 
 
@@ -96,8 +99,11 @@ def main():
     ref = {k: p.data().cpu().numpy() for k, p in net.collect_params().items()}
     dp_losses = [np.concatenate([dp[r][0][i] for r in range(world)]) for i in range(4)]
     worst, table, num, den = 0.0, [], 0.0, 0.0
+    # bf16 storage, real shards: the shards' statistics arrive in another summation order, which moves bf16 roundings of
+    # activations (2^-9 relative each) instead of fp32 ones - the same comparison at the bf16 tolerance
+    ltol = 2e-4 if (STORAGE == "fp32" or os.environ.get("VD_DP_DUP")) else 2e-2
     for i in range(4):
-        assert np.allclose(dp_losses[i], losses[i], rtol=2e-4, atol=2e-4), (i, dp_losses[i], losses[i])
+        assert np.allclose(dp_losses[i], losses[i], rtol=ltol, atol=ltol), (i, dp_losses[i], losses[i])
     for k, v in ref.items():
         # compare the UPDATE each side applied (weights and running statistics start identical): both sides compute it
         # in fp32 through 75 layers with different summation orders, so the bound is the gradient-parity tolerance of
@@ -121,11 +127,17 @@ def main():
     else:
         # real shards: per-shard partial sums change the summation order (1e-7), which can flip a LeakyReLU decision at
         # |pre-activation| ~ 0 and move one small gradient tensor by a few %; the update as a whole must agree
-        assert l2 < 2e-3, l2
-        bad = [(r, k) for r, k in table if r >= 0.2]
-        assert not bad, sorted(bad)[-5:]
+        if STORAGE == "bf16":
+            # measured 4.1e-2 on this 64x64 / 4-class fixture (its deepest BatchNorms see 8 samples per rank): the size of
+            # bf16 storage's own distance from the fp32 oracle (whole-gradient cosine 0.906 there), not of the
+            # exchange - the duplicate-shard form, which has the same collectives, is bit-identical
+            assert l2 < 1e-1, l2
+        else:
+            assert l2 < 2e-3, l2
+            bad = [(r, k) for r, k in table if r >= 0.2]
+            assert not bad, sorted(bad)[-5:]
     print("update L2 difference %.2e" % l2)
-    print("dp_equivalence ok: world=%d, %d tensors, worst relative difference %.2e" % (world, len(ref), worst))
+    print("dp_equivalence ok: storage=%s world=%d, %d tensors, worst relative difference %.2e" % (STORAGE, world, len(ref), worst))
 
 
 if __name__ == "__main__":

@@ -2135,8 +2135,17 @@ class YOLOV3(object):
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size(self.process_group)
-        if self.syncbn_scope and world > 1:
-            raise NotImplementedError("SyncBN with bf16 storage is not built")
+            # (as in _build_train: the gradient buckets get their own communicator when SyncBN's statistics all-reduces sit
+            # on the critical path of backward)
+            if (world > 1 and self.syncbn_scope and self.bucketed_allreduce and self._bucket_group is None
+                    and self.process_group is None):
+                self._bucket_group = torch.distributed.new_group()
+
+        def cut(segments, p_, fn):
+            segments.append(p_)
+            segments.append(fn)
+            return Program()
+
         hb = lambda c: c if (c == 32 or c % 64 == 0) else round_up(c, 64)      # head pitch: the data gradient's K dimension
         # algorithmic bytes of a launch: every operand tensor once, at 2 bytes per element
         fl = lambda n_, kind: dict(self._flops(n_, B, H, W, kind), bytes=self._flops(n_, B, H, W, kind)['bytes'] / 2)
@@ -2229,8 +2238,16 @@ class YOLOV3(object):
                 z = out
             fin = (n.gamma.data_ptr(), n.beta.data_ptr(), BN_EPS, BN_MOMENTUM, n.rmean.data_ptr(), n.rvar.data_ptr(),
                    n.b_scale.data_ptr(), n.b_shift.data_ptr(), n.b_mean.data_ptr(), n.b_invstd.data_ptr())
-            seg.add('vd_bn_sum_finalize', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), float(M), *fin,
-                    ws.data_ptr(), ws_bytes)
+            if self._syncbn(n):
+                # SyncBN (train_yolov3.py:347-354): the fp64 [sum x, sum x^2] of the fp32 accumulators, summed over the
+                # ranks, then one finalize on the global count - the same exchange unit as the fp32-storage plan
+                seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
+                sums = n.sums
+                seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
+                seg.add('vd_bn_finalize', n.sums.data_ptr(), float(M * world), n.cout, *fin)
+            else:
+                seg.add('vd_bn_sum_finalize', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), float(M), *fin,
+                        ws.data_ptr(), ws_bytes)
             res = bufs[n.residual].data_ptr() if n.residual else None
             seg.add('vd_bn_apply_leaky_bf16', z.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(), res,
                     bufs[n.dst].data_ptr(), M, n.cout, LEAKY_SLOPE,
@@ -2353,10 +2370,15 @@ class YOLOV3(object):
                     seg.add('vd_bn_bwd_reduce_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
                             n.b_mean.data_ptr(), n.b_invstd.data_ptr(), M, n.cout, LEAKY_SLOPE, n.sums2.data_ptr(), ws.data_ptr(), ws_bytes)
                     seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
+                count = float(M)
+                if self._syncbn(n):          # [sum g, sum g xhat] over the ranks (the local gamma / beta gradients came first)
+                    s2 = n.sums2
+                    seg = cut(bwd, seg, lambda s2=s2: torch.distributed.all_reduce(s2, group=self.process_group))
+                    count = float(M * world)
                 if side is not None and dz_free[slot] is not None:
                     seg.add_py(ev_wait(dz_free[slot], False))
                 seg.add('vd_bn_bwd_apply_bf16', z.data_ptr(), dy.data_ptr(), n.b_scale.data_ptr(), n.b_shift.data_ptr(),
-                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), float(M), M, n.cout, LEAKY_SLOPE, dz.data_ptr())
+                        n.b_mean.data_ptr(), n.b_invstd.data_ptr(), n.sums2.data_ptr(), count, M, n.cout, LEAKY_SLOPE, dz.data_ptr())
             if w_train:
                 if n.stem:
                     wargs = ('vd_stem_wgrad_bf16', bufs['in'].data_ptr(), dz.data_ptr(), n.co_pad, n.gwp.data_ptr(), B, Hi, Wi)
