@@ -204,6 +204,17 @@ def main():
         phases = {"fwd_loss_ms": timed(lambda: net(x, gt, *tgd)), "bwd_ms": timed(net.backward),
                   "allreduce_ms": timed(net.allreduce_grads),
                   "sgd_ms": timed(lambda: net.sgd_step(lr, mom, wd, batch_size=B * world))}
+        if a.syncbn and (world > 1 or force_dist):
+            # SyncBN: what the per-layer statistics exchanges cost the step - the same two phases with the exchanges
+            # suppressed (every rank alike; the statistics are then local, which only this diagnostic step sees)
+            net._syncbn_suppress = True
+            f0, b0 = timed(lambda: net(x, gt, *tgd)), timed(net.backward)
+            net._syncbn_suppress = False
+            net._dp_stats["syncbn_exchanges"] = 0
+            f1, b1 = timed(lambda: net(x, gt, *tgd)), timed(net.backward)
+            phases["syncbn"] = {"scope": a.syncbn, "exchanges_per_step": net._dp_stats.get("syncbn_exchanges", 0),
+                                "fwd_bwd_ms": round(f1 + b1, 3), "fwd_bwd_without_exchanges_ms": round(f0 + b0, 3),
+                                "syncbn_exposed_ms": round(max(0.0, f1 + b1 - f0 - b0), 3)}
         if world > 1 or force_dist:
             # Diagnostics of the gradient exchange (the driver computes scaling efficiency itself from `value`): how much of
             # the all-reduce the backward pass does NOT hide, and what the fabric delivers on the whole arena.

@@ -60,6 +60,14 @@ class Program:
         self.meta.append(None)
         self.streams.append(None)
 
+    def add_coll(self, fn):
+        """a collective (SyncBN's statistics all-reduce) as a record of the program: enqueued in place between the launches
+        it sits between - the replay loop never leaves the program for it - and replayed by run_timed as well, so the ranks
+        of a job stay in step whichever replay form they run"""
+        self.recs.append((None, fn, ()))
+        self.meta.append(dict(kind='collective'))
+        self.streams.append(None)
+
     def hold(self, *objs):
         self.keep.extend(objs)
 
@@ -82,6 +90,8 @@ class Program:
         out = []
         for (fname, fn, args), meta in zip(self.recs, self.meta):
             if fname is None:
+                if meta and meta.get('kind') == 'collective':
+                    fn()
                 continue
             a = [x.value if isinstance(x, Slot) else x for x in args]
             if fname in select:
@@ -1211,6 +1221,16 @@ class YOLOV3(object):
             ws = self._sk_ws[stream_idx] = ops.streamk_workspace(self.device)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
 
+    def _syncbn_exchange(self, t):
+        """the SyncBN collective of one layer and direction: sum all-reduce of its fp64 [2C] vector over the ranks"""
+        def f():
+            if getattr(self, '_syncbn_suppress', False):          # (bench.py times a step without the exchanges)
+                return
+            torch.distributed.all_reduce(t, group=self.process_group)
+            if getattr(self, '_dp_stats', None) is not None:
+                self._dp_stats['syncbn_exchanges'] = self._dp_stats.get('syncbn_exchanges', 0) + 1
+        return f
+
     def _add_sel_add_fwd(self, prog, n, bufs, B):
         """Forward launches of a SelNode / AddNode (the same in inference and training)."""
         am = lambda t: bufs['amax:' + t].data_ptr()
@@ -1606,7 +1626,8 @@ class YOLOV3(object):
     def _syncbn(self, n):
         if not self.syncbn_scope or not torch.distributed.is_available() or not torch.distributed.is_initialized():
             return False
-        if torch.distributed.get_world_size(self.process_group) < 2:
+        # (VD_FORCE_DIST=1, bench.py / tests: the exchange runs on a single rank too - the RCCL call pattern of an N-rank job)
+        if torch.distributed.get_world_size(self.process_group) < 2 and __import__('os').environ.get("VD_FORCE_DIST", "0") != "1":
             return False
         if self.syncbn_scope == 'all':
             return True
@@ -1647,11 +1668,6 @@ class YOLOV3(object):
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
         self._add_input_stage(seg, bufs, B, H, W)
-
-        def cut(segments, p, fn):
-            segments.append(p)
-            segments.append(fn)
-            return Program()
 
         amx = lambda t: bufs['amax:' + t].data_ptr()
         for n in self.nodes:
@@ -1726,8 +1742,7 @@ class YOLOV3(object):
                     seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), ws.data_ptr(),
                             ws_bytes)
                 if self._syncbn(n):
-                    sums = n.sums
-                    seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
+                    seg.add_coll(self._syncbn_exchange(n.sums))
                     count = float(M * world)
                 seg.add('vd_bn_finalize', n.sums.data_ptr(), count, n.cout, *fin)
             res = bufs[n.residual].data_ptr() if n.residual else None
@@ -1931,8 +1946,7 @@ class YOLOV3(object):
                     seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
                 count = float(M)
                 if self._syncbn(n):
-                    s2 = n.sums2
-                    seg = cut(bwd, seg, lambda s2=s2: torch.distributed.all_reduce(s2, group=self.process_group))
+                    seg.add_coll(self._syncbn_exchange(n.sums2))
                     count = float(M * world)
                 if side is not None and dz_free[slot] is not None:
                     seg.add_py(ev_wait(dz_free[slot], False))       # the wgrad that read this scratch has finished
@@ -2141,11 +2155,6 @@ class YOLOV3(object):
                     and self.process_group is None):
                 self._bucket_group = torch.distributed.new_group()
 
-        def cut(segments, p_, fn):
-            segments.append(p_)
-            segments.append(fn)
-            return Program()
-
         hb = lambda c: c if (c == 32 or c % 64 == 0) else round_up(c, 64)      # head pitch: the data gradient's K dimension
         # algorithmic bytes of a launch: every operand tensor once, at 2 bytes per element
         fl = lambda n_, kind: dict(self._flops(n_, B, H, W, kind), bytes=self._flops(n_, B, H, W, kind)['bytes'] / 2)
@@ -2242,8 +2251,7 @@ class YOLOV3(object):
                 # SyncBN (train_yolov3.py:347-354): the fp64 [sum x, sum x^2] of the fp32 accumulators, summed over the
                 # ranks, then one finalize on the global count - the same exchange unit as the fp32-storage plan
                 seg.add('vd_bn_sum_partials', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), ws.data_ptr(), ws_bytes)
-                sums = n.sums
-                seg = cut(fwd, seg, lambda sums=sums: torch.distributed.all_reduce(sums, group=self.process_group))
+                seg.add_coll(self._syncbn_exchange(n.sums))
                 seg.add('vd_bn_finalize', n.sums.data_ptr(), float(M * world), n.cout, *fin)
             else:
                 seg.add('vd_bn_sum_finalize', stats_ws.data_ptr(), table_rows, n.cout, n.sums.data_ptr(), float(M), *fin,
@@ -2372,8 +2380,7 @@ class YOLOV3(object):
                     seg.add('vd_bn_param_grads', n.sums2.data_ptr(), n.cout, n.ggamma.data_ptr(), n.gbeta.data_ptr())
                 count = float(M)
                 if self._syncbn(n):          # [sum g, sum g xhat] over the ranks (the local gamma / beta gradients came first)
-                    s2 = n.sums2
-                    seg = cut(bwd, seg, lambda s2=s2: torch.distributed.all_reduce(s2, group=self.process_group))
+                    seg.add_coll(self._syncbn_exchange(n.sums2))
                     count = float(M * world)
                 if side is not None and dz_free[slot] is not None:
                     seg.add_py(ev_wait(dz_free[slot], False))
