@@ -180,6 +180,9 @@ int vd_conv_igemm_mtiles(const vd_conv_desc* d);
  * accumulators before they are rounded to bf16 - [vd_conv_igemm_bf16_mtiles(d)][2 * Co] floats, as vd_conv_igemm writes
  * them.  d->tile: 0 = default, 1..13 = tile variant (256x256 .. 128x64; the host autotunes it). */
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
+/* VD_CONV_STREAMK in d->flags (with sk_ws / sk_ws_bytes) runs the launch as a persistent stream-K grid where that form
+ * applies (bf16 outputs, Ci % 64 == 0, enough tiles: as vd_conv_igemm); 1 when vd_conv_igemm_bf16(d, out_f32) would. */
+int vd_conv_igemm_bf16_streamk(const vd_conv_desc* d, int out_f32);
 int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d);
 /* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */
 int vd_pack_weight_bf16(const float* wp_f32, void* wp_bf16, int Co, int Co_pad, int Ci, int Ci_pad, int T,
@@ -295,6 +298,23 @@ int vd_bn_bwd_apply(const float* x, const float* dy, const float* scale, const f
                     const float* save_mean, const float* save_invstd,
                     const double* sums2, double count, int64_t M, int C, float slope,
                     float* dx, float* amax_out /* optional, as in vd_bn_apply_leaky */, void* stream);
+
+/* Operand-range guard of VD_MATH_F16X2.  That arithmetic scales a whole tensor by ONE power of two; elements more than
+ * ~2^18 below the tensor's max-abs are staged with fewer than 22 significant bits.  Dense tensors (activations, gradients
+ * behind a BatchNorm backward) only get there through their per-channel scales, which are known from the layer's vectors:
+ * per BatchNorm layer i, ratios[2i] = min_c / max_c of (|gamma_c| + |beta_c|) (the cell's output y), ratios[2i+1] the same
+ * of |scale_c| (= gamma_c * invstd_c: the gradient dz the layer's backward writes; scale may be NULL: ratio 1), and
+ * flags[2i+k] = ratios[2i+k] < thresh.  `items` is a DEVICE array.  The host reads the flags when it synchronises anyway
+ * and rebuilds the plans of flagged tensors' consumers in VD_MATH_SPLIT, whose bf16 pieces have fp32's exponent range
+ * (viddet_amd/model.py check_operand_ranges).  Sparse saturated tensors - the loss gradient - never run in VD_MATH_F16X2. */
+typedef struct {
+    const float* gamma;
+    const float* beta;
+    const float* scale;     /* gamma * invstd of the last training forward, or NULL */
+    int32_t C;
+    int32_t pad_;
+} vd_guard_item;
+int vd_range_guard(const vd_guard_item* items, int n, float thresh, float* ratios, int32_t* flags, void* stream);
 
 /* out[slot] = max(a[slot], b[slot]) over the sub-slots (b may be NULL: copy): the max-abs of a tensor assembled from, or
  * bounded by, other tensors (upsample+concat, temporal pooling / stacking) without another pass over it */

@@ -127,7 +127,7 @@ def test_configs1_detect_batch_32_frames_608(precision):
     tol = 1e-5 if precision == 'fp32' else 2e-2
     assert np.array_equal(take_ranks(idsB[:1], perm), ids1.cpu().numpy())
     assert float(np.abs(take_ranks(scB[:1], perm) - sc1.cpu().numpy()).max()) < tol
-    assert float(np.abs(take_ranks(bxB[:1], perm) - bx1.cpu().numpy()).max()) < (2e-3 if precision == 'fp32' else 2.0)
+    assert float(np.abs(take_ranks(bxB[:1], perm) - bx1.cpu().numpy()).max()) < (3e-3 if precision == 'fp32' else 2.0)
 
 
 def test_configs3_temporal_windows_batch_16_416():

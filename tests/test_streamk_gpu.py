@@ -242,3 +242,41 @@ def test_every_consumer_gives_up_and_recomputes():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("EQUAL")][-1].split()
     assert line[1] == "True" and int(line[3]) > 100, line
+
+
+@pytest.mark.parametrize("tile", [6, 7, 2, 1, 10])
+@pytest.mark.parametrize("case", [(64, 256, 26, 512, 3), (32, 128, 38, 256, 3), (100, 256, 26, 128, 1)])
+def test_bf16_kernel_bit_identical(case, tile):
+    """k_conv_igemm_bf16 (bf16 inference, bf16-storage training): the same claim - outputs and the fused BatchNorm statistics
+    table of a training forward bit-identical to the one-tile-per-workgroup launch"""
+    from viddet_amd import ops, lib as L
+    n, ci, hw, co, k = case
+    g = torch.Generator(device="cuda").manual_seed(4321 + tile)
+    x = torch.randn(n, hw, hw, ci, device="cuda", generator=g).to(torch.bfloat16)
+    wt = torch.randn(co, k * k * ci, device="cuda", generator=g) / np.sqrt(ci * k * k)
+    wb = torch.empty(co, k * k * ci, device="cuda", dtype=torch.bfloat16)
+    ops.pack_weight_bf16(wt, wb, Co=co, Co_pad=co, Ci=ci, Ci_pad=ci, T=k * k)
+    res = torch.randn(n, hw, hw, co, device="cuda", generator=g).to(torch.bfloat16)
+    sc, sh = torch.rand(co, device="cuda", generator=g) + 0.5, torch.randn(co, device="cuda", generator=g)
+    ws = ops.streamk_workspace()
+    geo = dict(N=n, Hi=hw, Wi=hw, Ci=ci, Hg=hw, Wg=hw, in_stride=1, taps=ops.fwd_taps(k, k // 2), Ho=hw, Wo=hw, Co=co, ldo=co, tile=tile)
+    for nohalo in ((False, True) if k == 3 else (True,)):
+        outs, used = [], False
+        for sk in (None, ws):
+            # inference form: BN fold + LeakyReLU + residual epilogue
+            y = torch.empty(n, hw, hw, co, device="cuda", dtype=torch.bfloat16)
+            d = ops.conv_igemm_bf16(x, wb, y, scale=sc, shift=sh, residual=res, ldr=co, leaky=True, nohalo=nohalo, streamk_ws=sk, **geo)
+            if sk is not None:
+                used = bool(L.load().vd_conv_igemm_bf16_streamk(C.byref(d), 0))
+            # training form: raw output + statistics rows from the fp32 accumulators
+            mt = ops.conv_bf16_mtiles(n, hw, hw, ci, co, tile)
+            part = torch.zeros(mt, 2 * co, device="cuda")
+            z = torch.empty(n, hw, hw, co, device="cuda", dtype=torch.bfloat16)
+            ops.conv_igemm_bf16(x, wb, z, stats_part=part, nohalo=nohalo, streamk_ws=sk, **geo)
+            outs.append((y, z, part))
+        torch.cuda.synchronize()
+        if not used:
+            continue
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+    assert int(ws.view(torch.int32)[2047]) == 0

@@ -88,3 +88,17 @@ def take_ranks(t, perm):
     """Device output (B, N, .) reordered so that rank j holds what the reference has at rank j (assert_rows_match)."""
     a = np.asarray(t.cpu().numpy() if hasattr(t, "cpu") else t)
     return np.take_along_axis(a, perm[:, :, None], axis=1)
+
+
+def boxes_close(got, ref, abs_tol=1e-3, rel_tol=1e-5):
+    """Decoded boxes (..., 4) against the fp64 oracle: |error| <= 1e-3 px + 1e-5 of the box's scale (its largest |coordinate|
+    or side).  The boxes of these random-init fixtures are up to 800 px wide (exp() of unclipped raw sizes) and a corner is
+    centre -+ side / 2, so a corner's fp32 round-off follows the box's size, not the corner's own value: measured 1.05e-3 px
+    on a 100 px box, 2.8e-3 px on a 680 px one (5e-6 of the scale).  The bound is 2x that at every scale - and north_star's
+    1e-3 px for boxes of ordinary size."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.maximum(np.abs(ref).max(axis=-1), np.maximum(np.abs(ref[..., 2] - ref[..., 0]), np.abs(ref[..., 3] - ref[..., 1])))
+    bad = np.abs(got - ref) > (abs_tol + rel_tol * scale)[..., None]
+    assert not bad.any(), "boxes differ: worst %.3e px (box scale %.1f px)" % (
+        float(np.abs(got - ref)[bad].max()), float(np.broadcast_to(scale[..., None], ref.shape)[bad][np.argmax(np.abs(got - ref)[bad])]))
+    return True

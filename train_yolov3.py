@@ -324,6 +324,12 @@ def train(net, train_data, train_dataset, val_data, eval_metric, save_prefix, st
                 logger.info("[Epoch {}][Batch {}/{}], LR: {:.2E}, Speed: {:.3f} samples/sec, {}={:.3f}, {}={:.3f}, "
                             "{}={:.3f}, {}={:.3f}".format(epoch, i, num_batches, cur_lr,
                                                           batch_size / (time.time() - btic), n1, l1, n2, l2, n3, l3, n4, l4))
+                # the log line has synchronised: look at the operand ranges of the fp16-split arithmetic now (one small
+                # launch; a tensor whose channel scales have spread too far gets the range-exact arithmetic from here on)
+                flagged = net.check_operand_ranges()
+                if flagged:
+                    logger.info("range guard: %d tensor(s) moved to the range-exact arithmetic (%s)" % (
+                        len(flagged), ", ".join("%s %.1e" % kv for kv in sorted(flagged.items())[:4])))
             btic = time.time()
         torch.cuda.synchronize()
         (n1, l1), (n2, l2) = obj_metrics.get(), center_metrics.get()

@@ -426,6 +426,46 @@ int fixed_col_blocks(int64_t n4, int cvec) {
     return (int)nb;
 }
 
+// ---- operand-range guard of the fp16-split arithmetic (VD_MATH_F16X2, include/viddet_hip.h vd_range_guard) ------------
+// One workgroup per BatchNorm layer: the spread of the per-channel magnitudes of what the layer's cell writes,
+//   y channel c ~ |gamma_c| + |beta_c|   (y = leaky(gamma xhat + beta), xhat normalised over the batch)
+//   dz channel c ~ |scale_c|             (dz = scale_c (g - mean g - xhat mean g xhat), scale = gamma * invstd)
+// as ratio = min_c / max_c.  The fp16 split scales a TENSOR by one power of two: a channel 2^17 below the largest one is
+// staged with fewer than 22 significant bits, and an output that reads mostly that channel inherits the loss.
+__global__ void k_range_guard(const vd_guard_item* __restrict__ items, float thresh, float* __restrict__ ratios,
+                              int32_t* __restrict__ flags) {
+    const vd_guard_item it = items[blockIdx.x];
+    float lo[2] = {3.0e38f, 3.0e38f}, hi[2] = {0.f, 0.f};
+    for (int c = threadIdx.x; c < it.C; c += blockDim.x) {
+        const float u = fabsf(it.gamma[c]) + fabsf(it.beta[c]);
+        const float v = it.scale ? fabsf(it.scale[c]) : 1.f;
+        lo[0] = fminf(lo[0], u); hi[0] = fmaxf(hi[0], u);
+        lo[1] = fminf(lo[1], v); hi[1] = fmaxf(hi[1], v);
+    }
+    __shared__ float red[4][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = lo[0]; red[wave][1] = hi[0]; red[wave][2] = lo[1]; red[wave][3] = hi[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        float a = red[0][0], b = red[0][1], c2 = red[0][2], d = red[0][3];
+        for (int w = 1; w < nw; ++w) { a = fminf(a, red[w][0]); b = fmaxf(b, red[w][1]); c2 = fminf(c2, red[w][2]); d = fmaxf(d, red[w][3]); }
+        const float r0 = b > 0.f ? a / b : 1.f, r1 = d > 0.f ? c2 / d : 1.f;
+        ratios[2 * blockIdx.x] = r0;
+        ratios[2 * blockIdx.x + 1] = r1;
+        flags[2 * blockIdx.x] = r0 < thresh ? 1 : 0;
+        flags[2 * blockIdx.x + 1] = r1 < thresh ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -517,6 +557,13 @@ int vd_bn_sum_param_grads(const float* part, int nblk, int C, double* sums2, flo
     const int rc = vd_bn_sum_partials(part, nblk, C, sums2, ws, ws_bytes, stream);
     if (rc != VD_OK) return rc;
     return vd_bn_param_grads(sums2, C, dgamma, dbeta, stream);
+}
+
+int vd_range_guard(const vd_guard_item* items, int n, float thresh, float* ratios, int32_t* flags, void* stream) {
+    VD_REQUIRE(items && ratios && flags && n > 0 && thresh > 0.f && thresh < 1.f, "vd_range_guard: bad args");
+    hipLaunchKernelGGL(k_range_guard, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, items, thresh, ratios, flags);
+    VD_CHECK_LAUNCH("vd_range_guard");
+    return VD_OK;
 }
 
 int vd_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

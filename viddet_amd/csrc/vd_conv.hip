@@ -700,8 +700,8 @@ int vd_conv_igemm_streamk(const vd_conv_desc* d) {
 }
 
 int64_t vd_conv_igemm_streamk_ws_bytes(void) {
-    // the largest accumulator tile per slot: 256 x 128 at one workgroup per CU = 128 x 128 at two
-    return (int64_t)VD_SK_HEADER_BYTES + (int64_t)device_cus() * 256 * 128 * 4;
+    // the largest accumulator tile per slot: the 256 x 256 tiles of k_conv_igemm_bf16 at one workgroup per CU
+    return (int64_t)VD_SK_HEADER_BYTES + (int64_t)device_cus() * 256 * 256 * 4;
 }
 
 int vd_conv_igemm_mtiles(const vd_conv_desc* d) {

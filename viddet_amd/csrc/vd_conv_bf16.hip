@@ -10,725 +10,11 @@
 // Activations NHWC bf16 with the channel count padded to a multiple of 64; weights packed [Co_pad][T*Ci] bf16;
 // epilogue (BN-eval fold / bias, LeakyReLU, residual) in fp32, output bf16 (layers) or fp32 (prediction heads,
 // so the decode / NMS kernels are shared with the fp32 path).
-#include "vd_common.h"
-#include <stdlib.h>
+#include "vd_conv_igemm_bf16.h"
+
+int vd_igemm_bf16_sk_dispatch(const vd_conv_desc& d, int tile, hipStream_t s, bool query_only);     // vd_conv_bf16_sk.hip
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int ROW_B = 144;              // LDS row: 128 B of K + 16 B pad
-constexpr int KCH = 64;                 // bf16 channels per K-step
-
-__device__ __attribute__((aligned(64))) float g_zero_page_b[64];
-
-// developer build (-DVD_STAMP=1, tools/stamp_conv.py): wave 0 of one mid-grid workgroup records s_memtime at the
-// phase boundaries of the kernel
-#ifndef VD_STAMP
-#define VD_STAMP 0
-#endif
-#if VD_STAMP
-__device__ unsigned long long g_stamps[16];
-#define STAMP(i)                                                                          \
-    do {                                                                                  \
-        if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[i] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define STAMP(i)
-#endif
-
-// n / d for d >= 1 with rcp = 0xFFFFFFFF / d + 1: the multiply-high overshoots the quotient by at most one
-__device__ __forceinline__ unsigned udiv_rcp(unsigned n, unsigned d, unsigned rcp) {
-    unsigned q = d == 1u ? n : __umulhi(n, rcp);
-    q -= (q * d > n) ? 1u : 0u;
-    return q;
-}
-
-struct RowInfoB {
-    int64_t off;     // element offset (bf16) of (pixel of tap (0,0,0), channel 8*(tid&7))
-    unsigned mask;
-};
-
-// PAIR (Ci == 32, the two first-stage 3x3 convs): a K-step is still one 128-byte LDS row, made of TWO taps x 32
-// channels - the packed weight row [T][32] is already contiguous that way, and each lane's 16-byte chunk picks its
-// tap (chunk >> 2) - so 32-channel activations are stored unpadded and a 9-tap conv takes 5 K-steps instead of 9
-// half-empty ones.
-// HALO (3x3 stride-1 'same' geometry, 8-wave tiles): the activation operand is staged once per 64-channel chunk - the tile's
-// BM output pixels plus W + 1 pixels either side, 128 B per pixel - and the nine taps read it at row offsets dy * W + dx
-// (rows of taps outside the image read a zero row): (BM + 2 W + 2) / (9 BM) of the gather bytes.  Same scheme as the fp16-split
-// halo loop of vd_conv.hip (there with the rationale and the measurements); here the stream moves bf16 rows untouched.
-// BS (bf16-storage training, data gradients): the fused BatchNorm-backward reductions of vd_conv_igemm (vd_conv_desc.bs_*)
-// in the epilogue - sum g and sum g * xhat of the layer whose dy this launch completes, from the fp32 values before they
-// are rounded to bf16; z (p.bs_z) is a bf16 tensor of the output's geometry.
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR, bool HALO = false, bool BS = false>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
-                                                                  const int64_t zd_w) {
-    static_assert(!HALO || (WM * WN == 8 && !PAIR), "the halo loop exists for the 8-wave tiles");
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int NT = WM * WN * 64;
-    constexpr int RPP = NT / 8;
-    constexpr int AP = BM / RPP, BP = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile vs loader");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* As = smem_b;                       // [2][BM][ROW_B]
-    unsigned char* Bs = smem_b + 2 * BM * ROW_B;      // [2][BN][ROW_B]
-    const __bf16* in = reinterpret_cast<const __bf16*>(p.in);
-    const __bf16* wp = reinterpret_cast<const __bf16*>(p.wp);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
-    const int ntile = (p.Co + BN - 1) / BN;
-    const int lid = vd_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = lid % ntile, tile_m = lid / ntile;
-    const int Ktot = p.T * p.Ci;
-    const int lrow = tid >> 3;
-    const int lc8 = (tid & 7) * 8;            // bf16 element offset of this lane's 16-byte chunk (within the K-step)
-    const int lca = PAIR ? (tid & 3) * 8 : lc8;   // ... within its pixel's channel run
-    const int ptap = PAIR ? ((tid >> 2) & 1) : 0; // PAIR: which tap of the K-step's pair this lane gathers
-
-    STAMP(0);
-    // Row geometry.  The tap table sits in lane registers (lane t = tap t, read back with v_readlane) so the mask
-    // loop has no scalar-memory round trip per tap, and the two divisions per row are multiply-high by a reciprocal
-    // computed once (exact after one correction: see udiv_rcp).
-    const int tlane = lane < p.T ? lane : 0;
-    const int tap_dy = p.dy[tlane], tap_dx = p.dx[tlane], tap_dz = p.dz[tlane];
-    const unsigned rcp_w = 0xFFFFFFFFu / (unsigned)p.Wg + 1u, rcp_h = 0xFFFFFFFFu / (unsigned)p.Hg + 1u;
-    RowInfoB ri[AP];
-    int riy[AP], rix[AP], rfz[AP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int64_t m = (int64_t)tile_m * BM + lrow + RPP * i;
-        const unsigned mu = m < M ? (unsigned)m : 0u;
-        const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
-        const int gx = (int)(mu - t * (unsigned)p.Wg);
-        const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
-        const int gy = (int)(t - n_ * (unsigned)p.Hg);
-        const int n = (int)n_;
-        riy[i] = gy * p.in_stride;
-        rix[i] = gx * p.in_stride;
-        rfz[i] = p.Kfr == 1 ? 0 : n % p.Kfr;
-        ri[i].off = (int64_t)((n * p.Hi + riy[i]) * p.Wi + rix[i]) * p.Ci + lca;
-        ri[i].mask = 0u;
-    }
-    for (int t2 = 0; t2 < p.T; ++t2) {
-        const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2),
-                  dz = __builtin_amdgcn_readlane(tap_dz, t2);
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const bool ok = (unsigned)(riy[i] + dy) < (unsigned)p.Hi && (unsigned)(rix[i] + dx) < (unsigned)p.Wi &&
-                            (unsigned)(rfz[i] + dz) < (unsigned)p.Kfr;
-            ri[i].mask |= ok ? (1u << t2) : 0u;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < AP; ++i)
-        if ((int64_t)tile_m * BM + lrow + RPP * i >= M) ri[i].mask = 0u;
-    int64_t boff[BP];
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-        const int n = tile_n * BN + lrow + RPP * i;
-        boff[i] = (n < p.Co) ? (int64_t)n * Ktot + lc8 : (int64_t)-1;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // PD register sets of gathered tiles + a branch-free steady-state loop: see k_conv_igemm (vd_conv.hip)
-    constexpr int PD = ((WM * WN == 4 && TM * TN == 4) || TM * TN == 8 || AP + BP > 8) ? 2 : 3;
-    f32x4 ra[PD][AP], rb[PD][BP];
-    int t_tap = 0, c0 = 0;
-
-    const int64_t tap_eo = (int64_t)((tap_dz * p.Hi + tap_dy) * p.Wi + tap_dx) * p.Ci;   // lane t: tap t
-    const int tap_eo_lo = (int)(tap_eo & 0xffffffffll), tap_eo_hi = (int)(tap_eo >> 32);
-    auto tap_off = [&](int t) -> int64_t {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(tap_eo_lo, t);
-        const int hi = __builtin_amdgcn_readlane(tap_eo_hi, t);
-        return ((int64_t)hi << 32) | (int64_t)lo;
-    };
-    int64_t tap_soff = tap_off(0);
-    auto gload = [&](f32x4 (&ra)[AP], f32x4 (&rb)[BP]) {
-        if constexpr (PAIR) {
-            // t_tap counts K-steps; taps 2*t_tap and 2*t_tap+1 (bit T of every mask is clear: an odd tail is zeros)
-            const int t0 = 2 * t_tap;
-            const int64_t so0 = tap_off(t0), so1 = tap_off(t0 + 1 < p.T ? t0 + 1 : t0);
-            const int64_t soff = ptap ? so1 : so0;
-            const int tl = t0 + ptap;
-#pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const bool ok = (ri[i].mask >> tl) & 1u;
-                const int64_t sel = ok ? ri[i].off + soff : zd_in;
-                ra[i] = *reinterpret_cast<const f32x4*>(in + sel);
-            }
-            const int koff = t_tap * KCH;
-            const bool kin = koff + lc8 < Ktot;
-#pragma unroll
-            for (int i = 0; i < BP; ++i) {
-                const int64_t sel = (boff[i] >= 0 && kin) ? boff[i] + koff : zd_w;
-                rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
-            }
-            ++t_tap;
-            return;
-        }
-        const int64_t soff = tap_soff + c0;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const bool ok = (ri[i].mask >> t_tap) & 1u;
-            const int64_t sel = ok ? ri[i].off + soff : zd_in;
-            ra[i] = *reinterpret_cast<const f32x4*>(in + sel);
-        }
-        const int64_t koff = (int64_t)t_tap * p.Ci + c0;
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
-            rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
-        }
-        // taps innermost: the T taps of one channel chunk touch (almost) the same pixels, shifted (see vd_conv.hip)
-        ++t_tap;
-        if (t_tap >= p.T) {
-            t_tap = 0;
-            c0 += KCH;
-        }
-        tap_soff = tap_off(t_tap);
-    };
-    auto lstore = [&](int buf, const f32x4 (&ra)[AP], const f32x4 (&rb)[BP]) {
-        unsigned char* a = As + buf * BM * ROW_B;
-        unsigned char* b = Bs + buf * BN * ROW_B;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(a + (lrow + RPP * i) * ROW_B + (tid & 7) * 16) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(b + (lrow + RPP * i) * ROW_B + (tid & 7) * 16) = rb[i];
-    };
-    auto compute = [&](int buf) {
-        const unsigned char* a = As + buf * BM * ROW_B + (wm * TM * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
-        const unsigned char* b = Bs + buf * BN * ROW_B + (wn * TN * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * ROW_B + kc * 32);
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * ROW_B + kc * 32);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-        }
-    };
-
-    const int nks = PAIR ? (p.T + 1) / 2 : p.T * (p.Ci / KCH);
-    STAMP(1);
-    if constexpr (HALO) {
-        constexpr int HT = 9;
-        const int W = p.Wi;
-        const int R = BM + 2 * (W + 1);
-        const int ZROW = R, DROW = R + 1;                     // a zero row (taps outside the image), a sink row (idle stream slots)
-        const int ABUF = (R + 2) * ROW_B;
-        unsigned char* Ah = smem_b;                           // [2][R + 2][ROW_B]
-        unsigned char* Bh = smem_b + 2 * ABUF;                // [2][BN][ROW_B]
-        const int nchunk = p.Ci / KCH;
-        const int64_t m0 = (int64_t)tile_m * BM;
-        const int64_t Mtot = (int64_t)p.N * p.Hi * p.Wi;
-        if (tid < 16) *reinterpret_cast<f32x4*>(Ah + (tid >> 3) * ABUF + ZROW * ROW_B + (tid & 7) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        // halo stream: item (chunk c, slot s) = rows lrow + 64 s of chunk c's halo, 16 B per thread
-        unsigned hvalid = 0u;
-#pragma unroll
-        for (int s2 = 0; s2 < HT; ++s2) {
-            const int j = lrow + 64 * s2;
-            const int64_t pin = m0 - (W + 1) + j;
-            hvalid |= (j < R && (uint64_t)pin < (uint64_t)Mtot) ? (1u << s2) : 0u;
-        }
-        const int64_t hoff0 = (m0 - (W + 1) + lrow) * (int64_t)p.Ci + lc8;
-        const int64_t hslot = 64ll * p.Ci;
-        const int hl0 = lrow * ROW_B + (tid & 7) * 16;
-        const int hsink = (DROW - lrow) * ROW_B;
-        auto hload = [&](int c, int s) -> f32x4 {
-            const bool ok = ((hvalid >> s) & 1u) && c < nchunk;
-            const int64_t sel = ok ? hoff0 + (int64_t)s * hslot + (int64_t)c * KCH : zd_in;
-            return *reinterpret_cast<const f32x4*>(in + sel);
-        };
-        auto hstore = [&](const f32x4 v, int c, int s) {
-            const int ro_ = (c & 1) * ABUF + (((hvalid >> s) & 1u) ? s * 64 * ROW_B : hsink);
-            *reinterpret_cast<f32x4*>(Ah + ro_ + hl0) = v;
-        };
-        int bt = 0, bc0 = 0;
-        auto gloadB = [&](f32x4 (&rb)[BP]) {
-            const int64_t koff = (int64_t)bt * p.Ci + bc0;
-#pragma unroll
-            for (int i = 0; i < BP; ++i) {
-                const int64_t sel = boff[i] >= 0 ? boff[i] + koff : zd_w;
-                rb[i] = *reinterpret_cast<const f32x4*>(wp + sel);
-            }
-            if (++bt >= HT) { bt = 0; bc0 += KCH; }
-        };
-        auto lstoreB = [&](int buf, const f32x4 (&rb)[BP]) {
-#pragma unroll
-            for (int i = 0; i < BP; ++i)
-                *reinterpret_cast<f32x4*>(Bh + (buf * BN + lrow + RPP * i) * ROW_B + (tid & 7) * 16) = rb[i];
-        };
-        // prologue: the whole halo of chunk 0 and the first weight tile requested together, the operand-row geometry under
-        // their latency
-        f32x4 t9[HT];
-#pragma unroll
-        for (int s2 = 0; s2 < HT; ++s2) t9[s2] = hload(0, s2);
-        gloadB(rb[0]);
-        int jbase[TM];
-        unsigned amask[TM];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int il = wm * TM * 32 + mi * 32 + (lane & 31);
-            const int64_t m = m0 + il;
-            const unsigned mu = m < M ? (unsigned)m : 0u;
-            const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
-            const int gx = (int)(mu - t * (unsigned)p.Wg);
-            const unsigned n_ = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
-            const int gy = (int)(t - n_ * (unsigned)p.Hg);
-            unsigned mk = 0u;
-            for (int t2 = 0; t2 < HT; ++t2) {
-                const int dy = __builtin_amdgcn_readlane(tap_dy, t2), dx = __builtin_amdgcn_readlane(tap_dx, t2);
-                mk |= ((unsigned)(gy + dy) < (unsigned)p.Hi && (unsigned)(gx + dx) < (unsigned)p.Wi) ? (1u << t2) : 0u;
-            }
-            amask[mi] = m < M ? mk : 0u;
-            jbase[mi] = il + W + 1;
-        }
-        const int tap_ro = tap_dy * W + tap_dx;               // lane t: halo-row offset of tap t
-#pragma unroll
-        for (int s2 = 0; s2 < HT; ++s2) hstore(t9[s2], 0, s2);
-        lstoreB(0, rb[0]);
-        __syncthreads();
-        constexpr int HD = 3;                                 // halo items in flight: one request and one store per K-step
-        f32x4 hv[HD];
-        int hc = 1, hs = 0, sc = 1, ss = 0;                   // next item to request / to store (chunk, slot)
-#pragma unroll
-        for (int d = 0; d < HD; ++d) {
-            hv[d] = hload(hc, hs);
-            if (++hs >= HT) { hs = 0; ++hc; }
-        }
-#pragma unroll
-        for (int d = 1; d < PD; ++d)
-            if (d < nks) gloadB(rb[d]);
-        int cc = 0, ct = 0;                                   // chunk / tap of the step being multiplied
-        auto computeH = [&](int wbuf) {
-            const int ro = __builtin_amdgcn_readlane(tap_ro, ct);
-            const unsigned char* a[TM];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int j = ((amask[mi] >> ct) & 1u) ? jbase[mi] + ro : ZROW;
-                a[mi] = Ah + (cc & 1) * ABUF + j * ROW_B + 16 * (lane >> 5);
-            }
-            const unsigned char* b = Bh + wbuf * BN * ROW_B + (wn * TN * 32 + (lane & 31)) * ROW_B + 16 * (lane >> 5);
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                bf16x8 fa[TM], fb[TN];
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(a[mi] + kc * 32);
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * ROW_B + kc * 32);
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-            }
-            if (++ct >= HT) { ct = 0; ++cc; }
-        };
-        auto hstream = [&](int u) {
-            // store the item requested HD steps ago into the NEXT chunk's buffer (nobody reads it before the barrier that ends
-            // this chunk's last step), then reuse its registers for a new request; items past the last chunk read the zero
-            // page and land in the sink row or in a buffer nobody reads any more: no conditional memory operation
-            hstore(hv[u % HD], sc, ss);
-            if (++ss >= HT) { ss = 0; ++sc; }
-            hv[u % HD] = hload(hc, hs);
-            if (++hs >= HT) { hs = 0; ++hc; }
-        };
-        constexpr int UNH = 6;                                // = lcm(2 weight stages, PD in {2, 3}, HD)
-        static_assert(UNH % PD == 0 && UNH % HD == 0, "unroll vs register sets");
-        int ks = 0;
-        for (; ks + UNH + PD <= nks; ks += UNH) {
-#pragma unroll
-            for (int u = 0; u < UNH; ++u) {
-                gloadB(rb[u % PD]);
-                computeH(u & 1);
-                lstoreB((u + 1) & 1, rb[(u + 1) % PD]);
-                hstream(u);
-                __syncthreads();
-            }
-        }
-        for (; ks < nks; ks += UNH) {
-#pragma unroll
-            for (int u = 0; u < UNH; ++u) {
-                if (ks + u < nks) {
-                    if (ks + u + PD < nks) gloadB(rb[u % PD]);
-                    computeH(u & 1);
-                    if (ks + u + 1 < nks) lstoreB((u + 1) & 1, rb[(u + 1) % PD]);
-                    hstream(u);
-                    __syncthreads();
-                }
-            }
-        }
-    } else {
-    gload(ra[0], rb[0]);
-    STAMP(2);
-    lstore(0, ra[0], rb[0]);
-    __syncthreads();
-    STAMP(3);
-    constexpr int UN = (PD % 2 == 0) ? PD : 2 * PD;
-#pragma unroll
-    for (int d = 1; d < PD; ++d)
-        if (d < nks) gload(ra[d], rb[d]);
-    int ks = 0;
-    if (nks >= PD) {
-        for (; ks + UN + PD <= nks; ks += UN) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                gload(ra[u % PD], rb[u % PD]);
-                compute(u & 1);
-                lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
-                __syncthreads();
-            }
-        }
-    }
-    for (; ks < nks; ks += UN) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (ks + u < nks) {
-                if (ks + u + PD < nks) gload(ra[u % PD], rb[u % PD]);
-                compute(u & 1);
-                if (ks + u + 1 < nks) lstore((u + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
-                __syncthreads();
-            }
-        }
-    }
-    }   // !HALO
-
-    STAMP(4);
-    // ---- epilogue (fp32 math).  Per wave, one 32x32
-    // accumulator tile at a time is transposed through a private LDS patch so that each lane owns 4 consecutive
-    // columns of 4 rows: scale/shift/LeakyReLU/residual on 4-vectors and 8-byte (bf16 x4) or 16-byte (fp32 heads)
-    // stores instead of 2 bytes per lane.
-    const __bf16* res = reinterpret_cast<const __bf16*>(p.residual);
-    constexpr int SLD = 36;
-    float* stg = reinterpret_cast<float*>(smem_b) + wave * (32 * SLD);
-    const int erow = lane >> 3, ec4 = (lane & 7) * 4;
-    const bool has_aff = p.flags & VD_EPI_AFFINE, has_res = p.flags & VD_EPI_RESIDUAL, has_leaky = p.flags & VD_EPI_LEAKY;
-    // output pixel of GEMM row m: the row itself (forward, stride-1 data gradients) or the strided / offset pixel of a
-    // stride-2 data gradient's parity class (vd_conv.hip has the same map)
-    const bool direct = (p.out_stride == 1 && p.out_oy == 0 && p.out_ox == 0 && p.Ho == p.Hg && p.Wo == p.Wg);
-    auto out_pix = [&](int64_t m) -> int64_t {
-        if (direct) return m;
-        const unsigned mu = (unsigned)m;
-        const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
-        const int gx = (int)(mu - t * (unsigned)p.Wg);
-        const unsigned n = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
-        const int gy = (int)(t - n * (unsigned)p.Hg);
-        return ((int64_t)n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
-    };
-    float bs_acc1[BS ? TN : 1][4], bs_acc2[BS ? TN : 1][4];      // BS: sum g / sum g * xhat of this lane's columns
-#pragma unroll
-    for (int ni = 0; ni < (BS ? TN : 1); ++ni)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bs_acc1[ni][e] = bs_acc2[ni][e] = 0.f;
-    const bool vec_ok = (p.ldo % 4 == 0) && ((uintptr_t)p.out % 16 == 0) && (p.Co % 4 == 0) &&
-                        (!has_res || ((p.ldr % 4 == 0) && ((uintptr_t)p.residual % 8 == 0))) &&
-                        (!has_aff || (((uintptr_t)p.scale | (uintptr_t)p.shift) % 16 == 0));
-    if (vec_ok) {
-        // Straight-line path (every layer of the network): all scale/shift and residual loads are issued first, then
-        // each 32x32 accumulator block goes through the wave's LDS patch (LDS is in order within a wave, so the
-        // compiler barrier is all the synchronisation a block needs) and is stored without ever waiting on a store.
-        f32x4 sc[TN], sh[TN];
-        int colv[TN];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
-            colv[ni] = col < p.Co ? col : -1;
-            const int cc = col < p.Co ? col : 0;
-            sc[ni] = (has_aff && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + cc) : f32x4{1.f, 1.f, 1.f, 1.f};
-            sh[ni] = (has_aff && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        const bool bstat = BS && p.bs_part != nullptr;
-        const __bf16* bz = reinterpret_cast<const __bf16*>(p.bs_z);
-        f32x4 qsc[BS ? TN : 1], qsh[BS ? TN : 1], qmu[BS ? TN : 1], qis[BS ? TN : 1];
-        bf16x4 zv[BS ? TM : 1][BS ? TN : 1][4];
-        if (BS) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int cc = colv[ni] < 0 ? 0 : colv[ni];
-                const f32x4 z0 = {0.f, 0.f, 0.f, 0.f};
-                qsc[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_scale + cc) : z0;
-                qsh[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_shift + cc) : z0;
-                qmu[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_mean + cc) : z0;
-                qis[ni] = bstat ? *reinterpret_cast<const f32x4*>(p.bs_invstd + cc) : z0;
-            }
-            if (bstat) {
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
-                            m = m < M ? m : M - 1;
-                            zv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(bz + out_pix(m) * p.ldo + (colv[ni] < 0 ? 0 : colv[ni]));
-                        }
-            }
-        }
-        bf16x4 rv[TM][TN][4];
-        if (has_res) {
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
-                        m = m < M ? m : M - 1;
-                        rv[mi][ni][i] = *reinterpret_cast<const bf16x4*>(res + out_pix(m) * p.ldr + (colv[ni] < 0 ? 0 : colv[ni]));
-                    }
-        }
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                f32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(stg + (erow + 8 * i) * SLD + ec4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
-                    f32x4 t = v[i];
-                    if (has_aff) t = t * sc[ni] + sh[ni];
-                    if (has_leaky) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * p.slope;
-                    }
-                    if (has_res) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] += (float)rv[mi][ni][i][e];
-                    }
-                    if (BS && bstat) {
-                        const bool ok = m < M && colv[ni] >= 0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float z = (float)zv[mi][ni][i][e];
-                            const float u = z * qsc[ni][e] + qsh[ni][e];
-                            float g = u > 0.f ? t[e] : t[e] * p.bs_slope;
-                            g = ok ? g : 0.f;
-                            bs_acc1[ni][e] += g;
-                            bs_acc2[ni][e] += g * (z - qmu[ni][e]) * qis[ni][e];
-                        }
-                    }
-                    if (m < M && colv[ni] >= 0) {
-                        const int64_t op = out_pix(m);
-                        if (OUT_F32) *reinterpret_cast<f32x4*>(p.out + op * p.ldo + colv[ni]) = t;
-                        else {
-                            bf16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)t[e];
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + op * p.ldo + colv[ni]) = o;
-                        }
-                    }
-                }
-            }
-    } else {
-        // general path (odd leading dimensions / unaligned pointers): element-wise tails
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
-            const int nvalid = p.Co - col;
-            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-            if (has_aff) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nvalid) {
-                        if (p.scale) sc[e] = p.scale[col + e];
-                        if (p.shift) sh[e] = p.shift[col + e];
-                    }
-            }
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[mi][ni][r];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = erow + 8 * i;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SLD + ec4);
-                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + row;
-                    if (nvalid <= 0 || m >= M) continue;
-                    const int64_t op = out_pix(m);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (e < nvalid) {
-                            float t = v[e];
-                            if (has_aff) t = t * sc[e] + sh[e];
-                            if (has_leaky) t = t > 0.f ? t : t * p.slope;
-                            if (has_res) t += (float)res[op * p.ldr + col + e];
-                            if (OUT_F32) p.out[op * p.ldo + col + e] = t;
-                            else reinterpret_cast<__bf16*>(p.out)[op * p.ldo + col + e] = (__bf16)t;
-                        }
-                }
-            }
-        }
-    }
-    STAMP(5);
-    // ---- fused BatchNorm backward reductions: one row of the partial table [tile_m][2 * Co] per M tile (as k_conv_igemm)
-    if constexpr (BS) {
-        if (p.bs_part != nullptr) {
-            __syncthreads();        // every wave is done with its staging patch
-            float* red = reinterpret_cast<float*>(smem_b);      // [WM][BN][2]
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = bs_acc1[ni][e], b = bs_acc2[ni][e];
-                    a += __shfl_xor(a, 8);  b += __shfl_xor(b, 8);
-                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-                    if (lane < 8) {
-                        const int c = wn * TN * 32 + ni * 32 + ec4 + e;
-                        red[(wm * BN + c) * 2 + 0] = a;
-                        red[(wm * BN + c) * 2 + 1] = b;
-                    }
-                }
-            __syncthreads();
-            for (int c = tid; c < BN; c += NT) {
-                const int colc = tile_n * BN + c;
-                if (colc < p.Co) {
-                    float a = 0.f, b = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WM; ++w) {
-                        a += red[(w * BN + c) * 2 + 0];
-                        b += red[(w * BN + c) * 2 + 1];
-                    }
-                    float* dstp = p.bs_part + (int64_t)tile_m * 2 * p.Co;
-                    dstp[colc] = a;
-                    dstp[p.Co + colc] = b;
-                }
-            }
-        }
-    }
-    // ---- fused BatchNorm statistics (bf16-storage training forward): per-column sum / sum of squares of this block's raw
-    // conv outputs, from the fp32 ACCUMULATORS (before they are rounded to bf16), one row of the partial table
-    // [tile_m][2 * Co] per M tile - no atomics, vd_bn_sum_partials finishes in fp64 in a fixed order (as k_conv_igemm)
-    if (p.stats_part) {
-        __syncthreads();        // every wave is done with its staging patch
-        float* red = reinterpret_cast<float*>(smem_b);      // [WM][BN][2]
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float v = (m < M) ? acc[mi][ni][r] : 0.f;
-                    s1 += v;
-                    s2 += v * v;
-                }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lane < 32) {
-                const int c = wn * TN * 32 + ni * 32 + lane;
-                red[(wm * BN + c) * 2 + 0] = s1;
-                red[(wm * BN + c) * 2 + 1] = s2;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            const int col = tile_n * BN + c;
-            if (col < p.Co) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    s1 += red[(w * BN + c) * 2 + 0];
-                    s2 += red[(w * BN + c) * 2 + 1];
-                }
-                float* dstp = p.stats_part + (int64_t)tile_m * 2 * p.Co;
-                dstp[col] = s1;
-                dstp[p.Co + col] = s2;
-            }
-        }
-    }
-#if VD_STAMP
-    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[6] = wall_clock64();
-#endif
-}
-
-const float* zero_page_b() {
-    static const float* zp = nullptr;
-    if (!zp) {
-        void* q = nullptr;
-        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_b)) != hipSuccess) q = nullptr;
-        zp = (const float*)q;
-    }
-    return zp;
-}
-
-// LDS bytes of the halo loop: two halo buffers of BM + 2 (W + 1) rows (+ zero row + sink row) and two weight stages
-inline int64_t halo_lds_b(int BM, int BN, int W) { return 2ll * (BM + 2 * (W + 1) + 2) * ROW_B + 2ll * BN * ROW_B; }
-
-inline bool halo_ok_b(const vd_conv_desc& d, int BM, int BN) {
-    if ((d.flags & VD_MATH_NOHALO) || d.T != 9 || d.in_stride != 1 || d.Kfr != 1 || d.Hg != d.Hi || d.Wg != d.Wi || d.Ci % KCH)
-        return false;
-    for (int t = 0; t < 9; ++t)
-        if (d.dy[t] < -1 || d.dy[t] > 1 || d.dx[t] < -1 || d.dx[t] > 1 || d.dz[t] != 0) return false;
-    // nine stream slots of 64 rows; the epilogue's staging patches (36 KB) reuse the same LDS
-    return BM + 2 * (d.Wi + 1) <= 9 * 64 && halo_lds_b(BM, BN, d.Wi) <= 160 * 1024;
-}
-
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false, bool HALO = false, bool BS = false>
-void launch_b2(const vd_conv_desc& d, hipStream_t s) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int lds_gen = 2 * (BM + BN) * ROW_B;
-    const int lds = HALO ? (int)(halo_lds_b(BM, BN, d.Wi) > 8 * 32 * 36 * 4 ? halo_lds_b(BM, BN, d.Wi) : 8 * 32 * 36 * 4) : lds_gen;
-    static bool attr_done = false;
-    auto kfn = k_conv_igemm_bf16<WM, WN, TM, TN, OUT_F32, PAIR, HALO, BS>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  HALO ? 160 * 1024 : lds_gen);
-        attr_done = true;
-    }
-    const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
-    const int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
-    const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page_b());
-    const int64_t zd_in = zp - reinterpret_cast<const __bf16*>(d.in);
-    const int64_t zd_w = zp - reinterpret_cast<const __bf16*>(d.wp);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w);
-}
-
-template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false>
-void launch_b(const vd_conv_desc& d, hipStream_t s) {
-    if constexpr (!OUT_F32 && TM * TN <= 4) {
-        if (d.bs_part) {              // fused BatchNorm-backward reductions (the entry point keeps the other tiles out)
-            if constexpr (WM * WN == 8 && !PAIR) {
-                if (halo_ok_b(d, WM * TM * 32, WN * TN * 32)) return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, true, true>(d, s);
-            }
-            return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, false, true>(d, s);
-        }
-    }
-    if constexpr (WM * WN == 8 && !PAIR && TM * TN <= 4) {
-        if (halo_ok_b(d, WM * TM * 32, WN * TN * 32)) return launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, true>(d, s);
-    }
-    launch_b2<WM, WN, TM, TN, OUT_F32, PAIR, false>(d, s);
-}
 
 template <bool OUT_F32>
 void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
@@ -740,6 +26,8 @@ void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
         return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
     }
     if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
+    // VD_CONV_STREAMK: the persistent stream-K grid of the same tile (vd_conv_bf16_sk.hip) where it applies
+    if (!OUT_F32 && (d.flags & VD_CONV_STREAMK) && vd_igemm_bf16_sk_dispatch(d, tile, s, false) == 0) return;
     switch (tile) {
         // 14, 15: small four-wave tiles (37 / 28 KB of LDS: four or five workgroups per CU) for the short-K 1x1 layers, which
         // are HBM-bound and ran at half the HBM rate on the large tiles: one workgroup's load latency and output stores
@@ -830,6 +118,13 @@ static int bf16_tile_bm(const vd_conv_desc& d) {
         case 13: case 7: case 1: case 2: case 3: case 15: return 128;
         default: return 64;
     }
+}
+
+int vd_conv_igemm_bf16_streamk(const vd_conv_desc* d, int out_f32) {
+    if (!d || out_f32 || !(d->flags & VD_CONV_STREAMK) || d->Ci == 32) return 0;
+    int tile = d->tile;
+    if (tile <= 0 || tile > 15) tile = d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2);
+    return vd_igemm_bf16_sk_dispatch(*d, tile, nullptr, true) == 0 ? 1 : 0;
 }
 
 int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d) {

@@ -59,6 +59,10 @@ class WgradDesc(C.Structure):
     ]
 
 
+class GuardItem(C.Structure):
+    _fields_ = [("gamma", _fp), ("beta", _fp), ("scale", _fp), ("C", C.c_int32), ("pad_", C.c_int32)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [
         ("head", _fp * 3), ("g", C.c_int32 * 3), ("ldh", C.c_int32),
@@ -80,6 +84,7 @@ SIGNATURES = {
     "vd_conv_igemm_streamk_ws_bytes": (_i64, []),
     "vd_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _i, _p]),
     "vd_conv_igemm_bf16_mtiles": (_i, [C.POINTER(ConvDesc)]),
+    "vd_conv_igemm_bf16_streamk": (_i, [C.POINTER(ConvDesc), _i]),
     "vd_pack_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vd_stem_im2col_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_conv_wgrad_ws_bytes": (_i64, [C.POINTER(WgradDesc)]),
@@ -101,6 +106,7 @@ SIGNATURES = {
     "vd_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _p, _p, _i64, _p]),
     "vd_bn_param_grads": (_i, [_p, _i, _p, _p, _p]),
     "vd_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i64, _i, _f, _p, _p, _p]),
+    "vd_range_guard": (_i, [_p, _i, _f, _p, _p, _p]),
     "vd_amax": (_i, [_p, _i64, _p, _p]),
     "vd_amax_segments": (_i, [_p, _p, _i, _p, _p]),
     "vd_amax_merge": (_i, [_p, _p, _p, _p]),

@@ -104,6 +104,9 @@ class Program:
                     meta = dict(meta or {}, split=bool(d.flags & L.MATH_SPLIT), bf16=bool(d.flags & L.MATH_BF16),
                                 f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)),
                                 streamk=bool(fname == "vd_conv_igemm" and L.load().vd_conv_igemm_streamk(args[0])))
+                if fname == "vd_conv_igemm_bf16":
+                    meta = dict(meta or {}, tile=int(args[0]._obj.tile), nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO),
+                                streamk=bool(L.load().vd_conv_igemm_bf16_streamk(args[0], args[1])))
                     if fname == "vd_conv_wgrad":                # the halo-ring kernel (vd_wgrad_halo.hip) or the generic one
                         meta["wgrad_halo"] = bool(L.load().vd_conv_wgrad_uses_halo(args[0]))
                     if fname == "vd_conv_igemm" and meta.get("bytes"):
@@ -505,6 +508,48 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     d.flags = _TUNE_CACHE[key]
 
 
+def _tune_bf16_record(d, of32, key, tiles, halo_geo):
+    """Time the tile variants of one vd_conv_igemm_bf16 launch record in place - generic loop, halo-staged loop where it
+    exists, and the persistent stream-K form of the three fastest (VD_CONV_STREAMK: same bits) - and keep the best as
+    (tile, flag bits) under `key`."""
+    import os
+    lib = L.load()
+    s = L.stream_ptr()
+    mask = L.MATH_NOHALO | L.CONV_STREAMK
+    base = d.flags & ~mask
+    if key not in _TUNE_CACHE:
+        verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
+
+        def time_of(c, fl):
+            d.tile, d.flags = c, base | fl
+            L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if verbose:
+                fl_ = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
+                print("bf16 tune %s tile %d %s%s: %.3f ms %.0f TF" % (key[1:10], c, "generic" if fl & L.MATH_NOHALO else "halo",
+                                                                   " stream-K" if fl & L.CONV_STREAMK else "", t / 3, fl_), flush=True)
+            return t
+        ranked = []
+        for c in tiles:
+            for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
+                ranked.append((time_of(c, fl), (c, fl)))
+        ranked.sort()
+        if _streamk_on() and d.sk_ws and not of32:
+            for _, (c, fl) in list(ranked[:3]):
+                d.tile, d.flags = c, base | fl | L.CONV_STREAMK
+                if lib.vd_conv_igemm_bf16_streamk(C.byref(d), of32):
+                    ranked.append((time_of(c, fl | L.CONV_STREAMK), (c, fl | L.CONV_STREAMK)))
+            ranked.sort()
+        _TUNE_CACHE[key] = _TUNE_CACHE.agree(ranked[0][1] if ranked else (2, L.MATH_NOHALO))
+    d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
+
+
 def autotune_program(prog, reps=3):
     for (fname, fn, args) in prog.recs:
         if fname == 'vd_conv_igemm':
@@ -865,6 +910,7 @@ class YOLOV3(object):
         self._recording = False
         self._programs = {}
         self._sk_ws = {}           # stream-K hand-off workspaces by stream index (_set_streamk)
+        self._range_exact = set()  # operand tensors whose consumers never run the fp16-split arithmetic (see _build)
         self._fold_dirty = True
         self._stats_version = 1          # bumped whenever the BatchNorm running statistics move
         self._weights_version = 1        # bumped whenever the weights move; each training plan packs its own data-gradient
@@ -899,6 +945,14 @@ class YOLOV3(object):
         self._head_frames = self._k if self.temporal_out else 1
         self.input_tensors = [nm for nm, _, _ in ROUTE_TENSORS] if self.noback else ['in']
         self.conv_nodes = [n for n in self.nodes if isinstance(n, ConvNode)]
+        # The loss gradient (dhead: (sigmoid - target) x mask) is sparse and saturated - after a few hundred steps most of its
+        # entries sit 2^20 .. 2^30 below its largest ones, and an output of its consumers that reads only such entries (a
+        # background pixel of the data gradient) would be formed from operands the fp16 split has staged with a handful of
+        # bits.  Its consumers - the data and weight gradients of the three prediction convs, 2 % of the step's FLOPs - are
+        # therefore range-exact BY CONSTRUCTION (3-way bf16 split / fp32 MFMA), never chosen by timing.  Every other operand
+        # tensor is dense; those join this set through check_operand_ranges() when their channel scales spread too far.
+        self._range_exact = set('dz:' + n.name for n in self.conv_nodes if n.head)
+        self._guard = None
         # arena layout: [conv weights (fwd-packed) | bn gamma, beta, head bias]  -> wd / no_wd ranges
         off = 0
         for n in self.conv_nodes:
@@ -1205,11 +1259,52 @@ class YOLOV3(object):
             flags |= EPI_RESIDUAL
             d.residual = residual.data_ptr()
         d.flags, d.slope = flags, LEAKY_SLOPE
-        d.amax_in, d.amax_w = bufs['amax:' + n.src].data_ptr(), n.wamax.data_ptr()
+        d.amax_in, d.amax_w = self._amax_or_none(bufs, n.src), n.wamax.data_ptr()
         self._set_streamk(d, 0)
         if amax_out:                                   # inference: the epilogue publishes the max-abs of what it writes
             d.amax_out = bufs['amax:' + n.dst].data_ptr()
         return d
+
+    def _amax_or_none(self, bufs, name):
+        """max-abs slots of an operand tensor for the fp16-split arithmetic, or None where that arithmetic must not be used
+        for its consumers (`_range_exact`): without the slots a launch record runs the 3-way bf16 split or the fp32 MFMA,
+        whose operands keep fp32's exponent range"""
+        if name in self._range_exact:
+            return None
+        return bufs['amax:' + name].data_ptr()
+
+    def check_operand_ranges(self, thresh=2.0 ** -16):
+        """The data-driven half of the fp16 split's range rule (include/viddet_hip.h vd_range_guard).  One
+        small launch over the BatchNorm vectors of the network, then a read of its flags (synchronises: call it where the
+        host waits anyway - train_yolov3.py does at every log line).  A tensor whose per-channel scales spread over more
+        than 1 / thresh joins `_range_exact`; the plans are dropped and rebuilt with the range-exact arithmetic for its
+        consumers.  Returns {tensor name: min / max channel-scale ratio} of the newly flagged tensors."""
+        bn = [n for n in self.conv_nodes if n.bn]
+        if not bn:
+            return {}
+        if getattr(self, '_guard', None) is None:
+            arr = (L.GuardItem * len(bn))()
+            for i, n in enumerate(bn):
+                arr[i].gamma, arr[i].beta, arr[i].scale, arr[i].C = n.gamma.data_ptr(), n.beta.data_ptr(), n.b_scale.data_ptr(), n.cout
+            items = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self._guard = (items, torch.zeros(2 * len(bn), device=self.device), torch.zeros(2 * len(bn), dtype=torch.int32, device=self.device))
+        items, ratios, flags = self._guard
+        L.check(L.load().vd_range_guard(items.data_ptr(), len(bn), float(thresh), ratios.data_ptr(), flags.data_ptr(), L.stream_ptr()),
+                'vd_range_guard')
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.process_group) > 1:
+            # every rank takes the union: without SyncBN the ranks' invstd differ, and the ranks must run the same plans
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.process_group)
+        fl, ra = flags.cpu().numpy(), ratios.cpu().numpy()
+        new = {}
+        for i, n in enumerate(bn):
+            for k, name in ((0, n.dst), (1, 'dz:' + n.name)):
+                if fl[2 * i + k] and name not in self._range_exact:
+                    new[name] = float(ra[2 * i + k])
+        if new:
+            self._range_exact.update(new)
+            self._drop_plans()
+        return new
 
     def _set_streamk(self, d, stream_idx):
         """give a conv record the stream-K hand-off workspace of the stream it runs on (0 = the program's main stream,
@@ -1428,6 +1523,7 @@ class YOLOV3(object):
             wb = torch.empty(co_p * n.T * ci_p, dtype=BFT, device=dev)
             packs.append((n, wb, co_p, ci_p))
             d = ConvDesc()
+            self._set_streamk(d, 0)
             x = bufs[n.src]
             Hi, Wi = H // n.div_in, W // n.div_in
             Ho, Wo = H // n.div_out, W // n.div_out
@@ -1499,43 +1595,20 @@ class YOLOV3(object):
         import os
         if os.environ.get("VD_AUTOTUNE", "1") == "0":
             return
-        lib = L.load()
-        s = L.stream_ptr()
         for (fname, fn, args) in prog.recs:
             if fname != 'vd_conv_igemm_bf16':
                 continue
             d, of32 = args[0]._obj, args[1]
-            base = d.flags & ~L.MATH_NOHALO
+            base = d.flags & ~(L.MATH_NOHALO | L.CONV_STREAMK)
             key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.Kfr)
-            if key not in _TUNE_CACHE:
-                best, best_t = (2, 0), None
-                verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
-                one = d.T == 1           # 14 / 15: small four-wave tiles for the HBM-bound 1x1 layers
-                tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
-                         else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
-                         else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()) + ((14,) if one else ()))
-                # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
-                # does not apply) is timed against the generic one
-                halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0
-                for c in tiles:
-                    for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
-                        d.tile, d.flags = c, base | fl
-                        L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(3):
-                            lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
-                        e1.record()
-                        e1.synchronize()
-                        t = e0.elapsed_time(e1)
-                        if verbose:
-                            fl_ = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
-                            print("bf16 tune %s tile %d %s: %.3f ms %.0f TF" % (key[1:10], c, "generic" if fl else "halo", t / 3, fl_),
-                                  flush=True)
-                        if best_t is None or t < best_t:
-                            best, best_t = (c, fl), t
-                _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
-            d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
+            one = d.T == 1           # 14 / 15: small four-wave tiles for the HBM-bound 1x1 layers
+            tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+                     else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
+                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()) + ((14,) if one else ()))
+            # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
+            # does not apply) is timed against the generic one
+            halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0
+            _tune_bf16_record(d, of32, key, tiles, halo_geo)
         _TUNE_CACHE.save()
 
     # ------------------------------------------------------------------ inference
@@ -1990,7 +2063,7 @@ class YOLOV3(object):
                 wd_.in_stride = n.stride
                 ops._set_taps(wd_, n.taps())
                 wd_.Kfr, wd_.splits = (n.fr if n.kd > 1 else 1), 0
-                wd_.amax_in, wd_.amax_dout = amx(n.src), amx('dz:' + n.name)
+                wd_.amax_in, wd_.amax_dout = self._amax_or_none(bufs, n.src), self._amax_or_none(bufs, 'dz:' + n.name)
                 autotune_wgrad(wd_, ws.data_ptr(), ws_bytes)
                 seg.hold(wd_)
                 if side is not None:
@@ -2052,7 +2125,7 @@ class YOLOV3(object):
                 d.out_stride, d.out_oy, d.out_ox = n.stride, plan['py'], plan['px']
                 d.ldo = d.ldr = n.cin
                 d.flags, d.slope = (EPI_RESIDUAL if acc else 0), LEAKY_SLOPE
-                d.amax_in, d.amax_w = amx('dz:' + n.name), n.wamax.data_ptr()
+                d.amax_in, d.amax_w = self._amax_or_none(bufs, 'dz:' + n.name), n.wamax.data_ptr()
                 self._set_streamk(d, pi if (par is not None) else 0)
                 if acc:
                     d.residual = res_src.data_ptr()
@@ -2111,34 +2184,16 @@ class YOLOV3(object):
         import os
         if os.environ.get("VD_AUTOTUNE", "1") == "0":
             return
-        lib = L.load()
-        s = L.stream_ptr()
-        base = d.flags & ~L.MATH_NOHALO
+        base = d.flags & ~(L.MATH_NOHALO | L.CONV_STREAMK)
         key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.out_stride, bool(d.stats_part),
                bool(d.bs_part))
-        if key not in _TUNE_CACHE:
-            best, best_t = (0, L.MATH_NOHALO), None
-            # 14 / 15: the small four-wave tiles (64x64 / 128x32, four or five workgroups per CU) for the HBM-bound 1x1 layers
-            one = d.T == 1
-            tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
-                     else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
-                     else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()) + ((14,) if one else ()))
-            halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
-            for c in tiles:
-                for fl in ((0, L.MATH_NOHALO) if (halo_geo and c in (2, 3, 5, 6, 7, 10)) else (L.MATH_NOHALO,)):
-                    d.tile, d.flags = c, base | fl
-                    L.check(lib.vd_conv_igemm_bf16(C.byref(d), of32, s), 'vd_conv_igemm_bf16/tune')
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        lib.vd_conv_igemm_bf16(C.byref(d), of32, s)
-                    e1.record()
-                    e1.synchronize()
-                    t = e0.elapsed_time(e1)
-                    if best_t is None or t < best_t:
-                        best, best_t = (c, fl), t
-            _TUNE_CACHE[key] = _TUNE_CACHE.agree(best)
-        d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
+        # 14 / 15: the small four-wave tiles (64x64 / 128x32, four or five workgroups per CU) for the HBM-bound 1x1 layers
+        one = d.T == 1
+        tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+                 else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
+                 else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()) + ((14,) if one else ()))
+        halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
+        _tune_bf16_record(d, of32, key, tiles, halo_geo)
 
     def _build_train_bf16(self, B, H, W):
         """The training plan of `_build_train` on bf16 activation / gradient tensors (set_storage('bf16')).  Same schedule:
@@ -2226,6 +2281,7 @@ class YOLOV3(object):
                 wb = wb_arena[n.w_off:n.w_off + n.w_numel]
                 assert n.w_numel == n.co_pad * n.T * n.cin and n.w_off % 8 == 0
                 d = ConvDesc()
+                self._set_streamk(d, 0)
                 out = bufs[n.dst] if n.head else bufs['z:' + n.dst]
                 d.in_, d.wp, d.out = bufs[n.src].data_ptr(), wb.data_ptr(), out.data_ptr()
                 d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = B, Hi, Wi, n.cin, Ho, Wo, n.stride
@@ -2436,6 +2492,7 @@ class YOLOV3(object):
                 wbd = torch.empty(n.cin * T * kp, dtype=BFT, device=dev)
                 packs.append(('dgrad', n, plan, w32, wbd, n.cin, n.co_pad, kp, T))
                 d = ConvDesc()
+                self._set_streamk(d, 0)
                 d.in_, d.wp, d.out = dz.data_ptr(), wbd.data_ptr(), dsrc.data_ptr()
                 d.N, d.Hi, d.Wi, d.Ci = B, Ho, Wo, kp
                 d.Hg, d.Wg, d.in_stride = plan['Hg'], plan['Wg'], 1

@@ -146,7 +146,8 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
 
 
 def conv_igemm_bf16(x, wb, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo, out_stride=1, out_oy=0, out_ox=0,
-                    scale=None, shift=None, residual=None, ldr=0, leaky=False, slope=0.1, tile=0, stats_part=None, nohalo=False):
+                    scale=None, shift=None, residual=None, ldr=0, leaky=False, slope=0.1, tile=0, stats_part=None, nohalo=False,
+                    streamk_ws=None):
     """vd_conv_igemm_bf16: x / wb / residual bf16, out bf16 or fp32 (by its dtype); any output geometry; stats_part =
     fused BatchNorm statistics table [mtiles][2 * Co] (conv_bf16_mtiles)."""
     d = ConvDesc()
@@ -160,6 +161,9 @@ def conv_igemm_bf16(x, wb, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, W
     d.flags = (EPI_AFFINE if (scale is not None or shift is not None) else 0) | (EPI_LEAKY if leaky else 0) | \
               (EPI_RESIDUAL if residual is not None else 0) | (MATH_NOHALO if nohalo else 0)
     d.slope, d.stats_part = slope, ptr(stats_part)
+    if streamk_ws is not None:
+        d.flags |= L.CONV_STREAMK
+        d.sk_ws, d.sk_ws_bytes = ptr(streamk_ws), streamk_ws.numel() * streamk_ws.element_size()
     check(_lib().vd_conv_igemm_bf16(C.byref(d), 1 if out.dtype == torch.float32 else 0, _s()), "vd_conv_igemm_bf16")
     return d
 
