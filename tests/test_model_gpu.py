@@ -93,8 +93,13 @@ def _targets(rng, b, c, size, m):
     return gt, Y.prefetch_targets(size, size, grids, gt, ids, c)
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6)])     # the second: one 416x416 voc frame, full-size grids
-def test_training_step_matches_oracle(cfg):
+@pytest.mark.parametrize("cfg", [(2, 4, 64, 3), (1, 20, 416, 6), (3, 4, 64, 3, "chunks")])     # the second: one 416x416 voc frame, full-size grids
+def test_training_step_matches_oracle(cfg, monkeypatch):
+    # the third: the stride-2 data gradients cut into frame chunks (VD_S2_CHUNK_MB, model.py: one HBM read of dz instead of
+    # four at BASELINE's sizes) - forced here by a tiny chunk size, three frames in chunks of one and two
+    if len(cfg) == 5:
+        monkeypatch.setenv("VD_S2_CHUNK_MB", "0.3")
+        cfg = cfg[:4]
     b, c, size, m = cfg
     net, P = _mk_net(c, 6, obj_bias=-1.0)
     rng = np.random.default_rng(6)

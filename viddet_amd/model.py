@@ -1736,7 +1736,8 @@ class YOLOV3(object):
         for n in self.conv_nodes:
             if n.bn:
                 # (+ 8 rows: the four parity launches of a stride-2 data gradient round their tile counts up separately)
-                smax = max(smax, ((B * n.fr * (H // n.div_out) * (W // n.div_out) + 63) // 64 + 8) * 2 * n.cout)
+                # (+ 8 + 4 x 64 rows: every parity launch of every frame chunk rounds its tile count up separately)
+                smax = max(smax, ((B * n.fr * (H // n.div_out) * (W // n.div_out) + 63) // 64 + 8 + 256) * 2 * n.cout)
         stats_ws = torch.empty(smax, device=dev)
         # ---- forward: list of segments; a segment is a Program or a python callable (collectives)
         fwd, seg = [], Program()
@@ -2100,10 +2101,35 @@ class YOLOV3(object):
             fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _fuse_bwd_s2())) and
                             consumers[n.src][0] is n and pm.fr == n.fr) else None
             bs_rows = 0
-            # the four parity launches of a stride-2 data gradient write disjoint pixels and read the same dz: run them
-            # side by side on their own streams (VD_PARITY_STREAMS=1) so that they share dz in the L2s and fill each other's tails
-            par = None
-            if _parity_streams() and len(plans) == 4 and self.overlap_wgrad:
+            # Frame chunks of a stride-2 data gradient (VD_S2_CHUNK_MB > 0; default 0 = one launch per parity class): each of
+            # the four parity launches streams the WHOLE incoming gradient dz - 709 MB at 208 x 208 x 64 channels, batch 64 - and
+            # is HBM-bound on it (isolated: 5.9 TB/s on the one-tap class).  Cut into chunks of frames whose dz fits the 256 MB
+            # Infinity Cache beside the outputs, the second to fourth class of a chunk find dz there: one HBM read instead of four.
+            NF = B * n.fr
+            nchunks = 1
+            # (measured, same box, batch 64 / 416x416: off 1022.0 frames/s, 192 MB 1021.9, 96 MB 1018.6, 48 MB 991.5 - the
+            # four launches already share most of dz through the L2s / Infinity Cache when they run side by side on their
+            # four streams; the default stays off, the switch and its parity test stay as the record of the experiment)
+            chunk_mb = float(__import__('os').environ.get('VD_S2_CHUNK_MB', '0'))
+            if len(plans) == 4 and n.kd == 1 and chunk_mb > 0:
+                dz_mb = 4.0 * NF * Ho * Wo * n.co_pad / 1e6
+                nchunks = max(1, min(NF, int(math.ceil(dz_mb / chunk_mb))))
+            fchunk = (NF + nchunks - 1) // nchunks
+            nchunks = (NF + fchunk - 1) // fchunk
+            wpks = []
+            for plan in plans:
+                assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
+                wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
+                dgrad_packs.append((n, plan, wpk))
+                wpks.append(wpk)
+            in_img, out_img = Ho * Wo * n.co_pad * 4, Hi * Wi * n.cin * 4          # bytes per frame of dz / of d:src
+            for ch in range(nchunks):
+              f0 = ch * fchunk
+              fn_ = min(NF, f0 + fchunk) - f0
+              # the four parity launches of a stride-2 data gradient write disjoint pixels and read the same dz: run them
+              # side by side on their own streams (VD_PARITY_STREAMS=1) so that they share dz in the L2s and fill each other's tails
+              par = None
+              if _parity_streams() and len(plans) == 4 and self.overlap_wgrad:
                 if getattr(self, '_par_streams', None) is None:
                     self._par_streams = [torch.cuda.Stream() for _ in range(3)]
                 par = self._par_streams
@@ -2111,13 +2137,11 @@ class YOLOV3(object):
                 seg.add_py(lambda e=e_fork: e.record(torch.cuda.current_stream()))
                 for st in par:
                     seg.add_py(lambda e=e_fork, st=st: st.wait_event(e))
-            for pi, plan in enumerate(plans):
-                assert plan['taps'], "a parity class without taps would leave its gradient unwritten"
-                wpk = torch.empty(n.cin * len(plan['taps']) * n.co_pad, device=dev)
-                dgrad_packs.append((n, plan, wpk))
+              for pi, plan in enumerate(plans):
+                wpk = wpks[pi]
                 d = ConvDesc()
-                d.in_, d.wp, d.out = dz.data_ptr(), wpk.data_ptr(), dsrc.data_ptr()
-                d.N, d.Hi, d.Wi, d.Ci = B * n.fr, Ho, Wo, n.co_pad
+                d.in_, d.wp, d.out = dz.data_ptr() + f0 * in_img, wpk.data_ptr(), dsrc.data_ptr() + f0 * out_img
+                d.N, d.Hi, d.Wi, d.Ci = fn_, Ho, Wo, n.co_pad
                 d.Hg, d.Wg, d.in_stride = plan['Hg'], plan['Wg'], 1
                 ops._set_taps(d, plan['taps'])
                 d.Kfr = n.fr if n.kd > 1 else 1
@@ -2128,11 +2152,11 @@ class YOLOV3(object):
                 d.amax_in, d.amax_w = self._amax_or_none(bufs, 'dz:' + n.name), n.wamax.data_ptr()
                 self._set_streamk(d, pi if (par is not None) else 0)
                 if acc:
-                    d.residual = res_src.data_ptr()
+                    d.residual = res_src.data_ptr() + f0 * out_img
                 seg.hold(d, wpk)
                 nplans = n.stride * n.stride
                 if fuse_m is not None:
-                    d.bs_z = bufs['z:' + fuse_m.dst].data_ptr()
+                    d.bs_z = bufs['z:' + fuse_m.dst].data_ptr() + f0 * out_img
                     d.bs_scale, d.bs_shift = fuse_m.b_scale.data_ptr(), fuse_m.b_shift.data_ptr()
                     d.bs_mean, d.bs_invstd = fuse_m.b_mean.data_ptr(), fuse_m.b_invstd.data_ptr()
                     d.bs_part, d.bs_slope = stats_ws.data_ptr() + bs_rows * 2 * fuse_m.cout * 4, LEAKY_SLOPE
@@ -2142,15 +2166,15 @@ class YOLOV3(object):
                     assert mt * 2 * fuse_m.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
                 seg.add('vd_conv_igemm', C.byref(d), meta=dict(
                     kind='dgrad', node=n.name, k=n.k, stride=n.stride,
-                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * B * n.fr,
-                    bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans),
+                    flops=2.0 * n.cin * n.cout * len(plan['taps']) * plan['Hg'] * plan['Wg'] * fn_,
+                    bytes=self._flops(n, B, H, W, 'dgrad')['bytes'] / nplans * fn_ / NF),
                     stream=(par[pi - 1] if (par is not None and pi > 0) else None))
                 if par is not None and pi == len(plans) - 1:
                     for st in par:                                  # join before anything reads d:src or the partial table
                         e_join = torch.cuda.Event()
                         seg.add_py(lambda e=e_join, st=st: e.record(st))
                         seg.add_py(lambda e=e_join: torch.cuda.current_stream().wait_event(e))
-                if fuse_m is not None and pi == len(plans) - 1:
+                if fuse_m is not None and pi == len(plans) - 1 and ch == nchunks - 1:
                     seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
                             fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
                     fused_bwd.add(fuse_m.name)
