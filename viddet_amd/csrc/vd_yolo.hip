@@ -176,6 +176,106 @@ __global__ __launch_bounds__(256) void k_decode_filter(const vd_head_desc h, flo
     }
 }
 
+// Objectness-first form (round 4; the default).  A class score is sigmoid(cls) * sigmoid(obj) < sigmoid(obj), so an
+// (pixel, anchor) whose objectness fails valid_thresh has no passing class (exact) - and with a trained network (or
+// bench.py's calibrated random one) that is ~95 % of them.  k_decode_filter above streams every 1 KB head row through LDS to
+// find that out; here a LANE owns one (pixel, anchor), reads its ONE objectness logit (a 4-byte gather: three of the
+// row's eight 128-byte lines), and only the entries that pass have their class vector read - by the whole wave, 64
+// classes per load.  At batch 32 / 608x608 / 80 classes the kernel touches ~40 % of the head bytes and has no LDS
+// staging at all (16 KB of candidate buffer per workgroup: eight workgroups per CU hide the gather's latency).  Same
+// candidate set and row ids as k_decode_filter; the append order is arbitrary in both (vd_nms_topk keys by (score, row)).
+__global__ __launch_bounds__(256) void k_decode_filter_obj(const vd_head_desc h, float thresh, float* __restrict__ cand_score,
+                                                           int32_t* __restrict__ cand_row, int cap, int32_t* __restrict__ counts) {
+    __shared__ float lscore[DF_LCAP];
+    __shared__ int32_t lrow[DF_LCAP];
+    __shared__ int lcount, lfill, gbase;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int npred = 5 + h.C;
+    const int R0 = h.g[0] * h.g[0], R1 = h.g[1] * h.g[1], R2 = h.g[2] * h.g[2];
+    const int E = 3 * (R0 + R1 + R2);                 // (pixel, anchor) entries of one image
+    if (threadIdx.x == 0) {
+        lcount = 0;
+        lfill = 1 << 30;
+    }
+    __syncthreads();
+    const int estep = gridDim.x * 256;
+    // wave-uniform trip count: the class sweep below is a whole-wave affair
+    for (int e0 = blockIdx.x * 256 + (threadIdx.x & ~63); e0 < E; e0 += estep) {
+        const int e = e0 + lane;
+        const bool in = e < E;
+        const int r = in ? e / 3 : 0, a = in ? e - 3 * r : 0;
+        int s, pix, rowbase;
+        if (r < R0) { s = 0; pix = r; rowbase = 0; }
+        else if (r < R0 + R1) { s = 1; pix = r - R0; rowbase = h.C * 3 * R0; }
+        else { s = 2; pix = r - R0 - R1; rowbase = h.C * 3 * (R0 + R1); }
+        const int g = h.g[s];
+        const float* src = h.head[s] + ((int64_t)b * g * g + pix) * h.ldh + a * npred;
+        const float obj = in ? vd_sigmoid(src[4]) : 0.f;
+        unsigned long long todo = __ballot(in && obj > thresh);
+        while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            // lane l's entry, by every lane of the wave
+            const float* csrc = reinterpret_cast<const float*>(
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)(uintptr_t)src >> 32), l) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)(uintptr_t)src & 0xffffffffull), l));
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, obj), l));
+            const int rb = __builtin_amdgcn_readlane(rowbase, l), px = __builtin_amdgcn_readlane(pix, l),
+                      an = __builtin_amdgcn_readlane(a, l), gg3 = __builtin_amdgcn_readlane(g * g * 3, l);
+            for (int c0 = 0; c0 < h.C; c0 += 64) {
+                const int c = c0 + lane;
+                float score = 0.f;
+                bool pass = false;
+                if (c < h.C) {
+                    score = vd_sigmoid(csrc[5 + c]) * o;
+                    pass = score > thresh;
+                }
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const int n = (int)__popcll(m);
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&lcount, n);                  // LDS atomic
+                    base = __shfl(base, 0);
+                    const int rowid = rb + c * gg3 + px * 3 + an;
+                    if (base + n <= DF_LCAP) {
+                        if (pass) {
+                            const int slot = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+                            lscore[slot] = score;
+                            lrow[slot] = rowid;
+                        }
+                    } else {                                                        // LDS buffer full: publish directly
+                        int gb = 0;
+                        if (lane == 0) {
+                            atomicMin(&lfill, base);
+                            gb = atomicAdd(&counts[b], n);
+                        }
+                        gb = __shfl(gb, 0);
+                        if (pass) {
+                            const int slot = gb + (int)__popcll(m & ((1ull << lane) - 1ull));
+                            if (slot < cap) {
+                                cand_score[(int64_t)b * cap + slot] = score;
+                                cand_row[(int64_t)b * cap + slot] = rowid;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nl = lcount < lfill ? lcount : lfill;      // (see k_decode_filter)
+    if (threadIdx.x == 0) gbase = atomicAdd(&counts[b], nl);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += 256) {
+        const int slot = gbase + i;
+        if (slot < cap) {
+            cand_score[(int64_t)b * cap + slot] = lscore[i];
+            cand_row[(int64_t)b * cap + slot] = lrow[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // inference: top-k + per-class NMS, one workgroup per image
 // ------------------------------------------------------------------------------------------
@@ -216,12 +316,24 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
         // (B, C*P, 6) tensor gives.  Rows are unique, so keys are unique and exactly `topk` keys are
         // >= the selected one: rows tied at the threshold score are kept by row order, never by arrival order.
         if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_kth = (unsigned)topk; }
+        // The candidates' score bits are read ONCE, NLOC per thread, all requests in flight together (lists of up to
+        // NLOC x 1024 = 40960 candidates: 37 k per image at batch 32 / 608x608 with the calibrated 2 % pass rate); the nine
+        // sweeps below then run out of registers.  Reading them again from global memory in every sweep - one dependent L2
+        // round trip per 1024 candidates and sweep behind the LDS atomics - was ~90 us of this kernel's 220.  Longer lists
+        // keep the streaming form.
+        constexpr int NLOC = 40;
+        const bool loc = n <= NLOC * NMS_THREADS;
+        unsigned kreg[NLOC];
+#pragma unroll
+        for (int j = 0; j < NLOC; ++j) {
+            const int i = tid + j * NMS_THREADS;
+            kreg[j] = (loc && i < n) ? __float_as_uint(cs[i]) : 0u;
+        }
         for (int pass = 7; pass >= 0; --pass) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned phi = s_prefix_hi, plo = s_prefix_lo;
-            for (int i = tid; i < n; i += NMS_THREADS) {
-                const unsigned k = __float_as_uint(cs[i]);
+            auto digit = [&](int i, unsigned k) {
                 if (pass >= 4) {                       // score digits: prefix = the digits above this one
                     const int hs = 8 * (pass - 3);
                     if (pass == 7 || (k >> hs) == phi) atomicAdd(&hist[(k >> (8 * (pass - 4))) & 255u], 1u);
@@ -230,29 +342,73 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
                     const int hs = 8 * (pass + 1);
                     if (pass == 3 || (r >> hs) == plo) atomicAdd(&hist[(r >> (8 * pass)) & 255u], 1u);
                 }
+            };
+            // (wave-aggregated atomics for the leading digit - four or five distinct values - measured no faster: 0.165 vs 0.157 ms)
+            if (loc) {
+#pragma unroll
+                for (int j = 0; j < NLOC; ++j) {
+                    const int i = tid + j * NMS_THREADS;
+                    if (i < n) digit(i, kreg[j]);
+                }
+            } else {
+                for (int i = tid; i < n; i += NMS_THREADS) digit(i, __float_as_uint(cs[i]));
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned kth = s_kth, cum = 0;
-                int d = 255;
-                for (; d > 0; --d) {
-                    if (cum + hist[d] >= kth) break;
-                    cum += hist[d];
+            // the digit of the kth-largest key: the largest d >= 1 whose suffix count S(d) = sum_{b >= d} hist[b] reaches kth
+            // (else 0), by ONE wave - four bins per lane, a suffix scan over the lanes.  (One thread walking the 256 bins was a
+            // chain of 256 dependent LDS reads per sweep: ~8 us x 8 sweeps of a kernel whose whole budget is 200.)
+            if (tid < 64) {
+                const unsigned kth = s_kth;
+                const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const unsigned t = h0 + h1 + h2 + h3;
+                unsigned suf = t;                                   // inclusive suffix sum over lanes >= this one
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_down(suf, off);
+                    if (tid + off < 64) suf += o;
                 }
-                if (pass >= 4) s_prefix_hi = (phi << 8) | (unsigned)d;
-                else s_prefix_lo = (plo << 8) | (unsigned)d;
-                s_kth = kth - cum;
+                const unsigned S3 = suf - t + h3, S2 = S3 + h2, S1 = S2 + h1, S0 = S1 + h0;
+                int dl = -1;
+                unsigned above = 0;                                 // S(dl + 1)
+                if (S3 >= kth) { dl = 4 * tid + 3; above = suf - t; }
+                else if (S2 >= kth) { dl = 4 * tid + 2; above = S3; }
+                else if (S1 >= kth) { dl = 4 * tid + 1; above = S2; }
+                else if (S0 >= kth && tid > 0) { dl = 4 * tid; above = S1; }
+                const unsigned long long has = __ballot(dl >= 1);
+                int d = 0;
+                unsigned cum;
+                if (has) {
+                    const int top = 63 - (int)__builtin_clzll(has);
+                    d = __builtin_amdgcn_readlane(dl, top);
+                    cum = (unsigned)__builtin_amdgcn_readlane((int)above, top);
+                } else {
+                    cum = (unsigned)__builtin_amdgcn_readlane((int)S1, 0);        // nothing reaches kth above bin 0: S(1)
+                }
+                if (tid == 0) {
+                    if (pass >= 4) s_prefix_hi = (phi << 8) | (unsigned)d;
+                    else s_prefix_lo = (plo << 8) | (unsigned)d;
+                    s_kth = kth - cum;
+                }
             }
             __syncthreads();
         }
         const unsigned Ts = s_prefix_hi, Tr = s_prefix_lo;
-        for (int i = tid; i < n; i += NMS_THREADS) {
-            const unsigned k = __float_as_uint(cs[i]);
-            const unsigned r = 0xFFFFFFFFu - (unsigned)cr[i];
-            if (k > Ts || (k == Ts && r >= Tr)) {
+        auto take = [&](int i, unsigned k) {
+            if (k < Ts) return;
+            const unsigned row = (unsigned)cr[i];
+            if (k > Ts || (0xFFFFFFFFu - row) >= Tr) {
                 const unsigned slot = atomicAdd(&s_cnt, 1u);       // exactly topk <= SORT_N of them; the sort orders them
-                if (slot < SORT_N) skey[slot] = ((unsigned long long)(~k) << 32) | (unsigned int)cr[i];
+                if (slot < SORT_N) skey[slot] = ((unsigned long long)(~k) << 32) | row;
             }
+        };
+        if (loc) {
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) {
+                const int i = tid + j * NMS_THREADS;
+                if (i < n) take(i, kreg[j]);
+            }
+        } else {
+            for (int i = tid; i < n; i += NMS_THREADS) take(i, __float_as_uint(cs[i]));
         }
     }
     __syncthreads();
@@ -561,6 +717,17 @@ int vd_yolo_decode_filter(const vd_head_desc* h, float valid_thresh, float* cand
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * h->B, s) != hipSuccess) {
         vd_set_error("vd_yolo_decode_filter: memset failed");
         return VD_ELAUNCH;
+    }
+    // VD_DECODE_ROWS=1: the row-streaming form of rounds 1-3 (developer A/B); default: objectness first
+    static const bool rows_form = getenv("VD_DECODE_ROWS") && atoi(getenv("VD_DECODE_ROWS")) != 0;
+    if (!rows_form) {
+        const int64_t E = 3ll * (h->g[0] * h->g[0] + h->g[1] * h->g[1] + h->g[2] * h->g[2]);
+        int nbo = (int)vd_cdiv(E, 256 * 4);               // four entries per lane
+        if (nbo > 2048) nbo = 2048;
+        if (nbo < 1) nbo = 1;
+        hipLaunchKernelGGL(k_decode_filter_obj, dim3(nbo, h->B), dim3(256), 0, s, *h, valid_thresh, cand_score, cand_row, cap, counts);
+        VD_CHECK_LAUNCH("vd_yolo_decode_filter");
+        return VD_OK;
     }
     const int A = 3 * (5 + h->C);
     const int lds = 4 * (((A + 3) & ~3) + 4) * (int)sizeof(float);
