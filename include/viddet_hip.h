@@ -78,6 +78,16 @@ extern "C" {
  * results are bit-identical to the launch without the flag.  Needs vd_conv_desc.sk_ws / sk_ws_bytes; where the form does
  * not apply (too few tiles, workspace too small, another arithmetic) the flag is ignored.  vd_conv_igemm_streamk(d) tells. */
 #define VD_CONV_STREAMK  1024
+/* VD_CONV_PARITY4 (vd_conv_desc.flags, with VD_MATH_F16X2): the data gradient of a 3x3 / stride-2 / pad-1 convolution as
+ * ONE launch instead of four parity launches.  `in` = the incoming gradient dz [N, Hi, Wi, Ci = Cout], Hg = Hi, Wg = Wi,
+ * in_stride 1, T = 4 taps with (dy, dx) = (0,0), (0,1), (1,0), (1,1); Co = 4 * par_cin GEMM columns = (parity class c,
+ * channel), `wp` packed by vd_pack_weight_dgrad_s2; out = dx [N, Ho = 2 Hi, Wo = 2 Wi, ldo >= par_cin], out_stride 2: row q,
+ * class c goes to pixel (2 qy + (c >> 1), 2 qx + (c & 1)).  Epilogue: residual (accumulate) and the fused BatchNorm-backward
+ * reductions (bs_*: one table row [2 par_cin] per (M tile, column tile): vd_conv_igemm_mtiles() rows, the caller zeroes
+ * the table first); no affine / LeakyReLU / statistics.  par_mask: bit (4 * tap + class) set where that weight block is
+ * nonzero (vd_pack_weight_dgrad_s2 returns it).  Replaces autograd's backward of nn.Conv2D(strides=2),
+ * three_darknet.py:182-183. */
+#define VD_CONV_PARITY4  2048
 #define VD_SK_MAX_WG        2048     /* seam counters per workspace (the last one counts the polls that gave up: diagnostics) */
 #define VD_SK_HEADER_BYTES  16384    /* [VD_SK_MAX_WG] u32 hand-off counters + [VD_SK_MAX_WG] u32 consumed counts */
 #define VD_SK_TIMEOUT_TICKS 4000     /* bound of the hand-off poll in 10 ns ticks, after which the consumer recomputes */
@@ -160,6 +170,9 @@ typedef struct {
      * workspace between launches that may run at the same time (one per stream). */
     void*   sk_ws;
     int64_t sk_ws_bytes;
+    /* VD_CONV_PARITY4: channels per parity class, nonzero (tap, class) weight blocks */
+    int32_t par_cin;
+    int32_t par_mask;
 } vd_conv_desc;
 
 int vd_conv_igemm(const vd_conv_desc* d, void* stream);
@@ -250,6 +263,11 @@ int vd_pack_weight_fwd(const float* w_oihw, float* wp, int Co, int Co_pad, int C
 int vd_pack_weight_dgrad(const float* w_oihw, float* wp, int Co, int Co_pad, int Ci,
                          int kd, int kh, int kw, const int32_t* taps, int ntaps, int src_packed,
                          void* stream);
+/* VD_CONV_PARITY4 weight image from the fwd-packed weights [Co][9 * Ci] of a 3x3 conv: wp4 [4 * Ci][4 * Co_pad],
+ * wp4[(c * Ci + ci)][o * Co_pad + co] = w[co][ci][ky][kx] for the kernel tap (ky, kx) that output parity class c = 2 py + px
+ * reaches at gradient offset o = 2 dy + dx (py = 0: ky = 1 at dy = 0; py = 1: ky = 2 at dy = 0, ky = 0 at dy = 1; likewise
+ * px / kx / dx), zero where there is none.  Returns the 16-bit block mask through *par_mask (host pointer; a constant). */
+int vd_pack_weight_dgrad_s2(const float* wp_fwd, float* wp4, int Co, int Co_pad, int Ci, int32_t* par_mask, void* stream);
 /* packed gradient [Co_pad][T*Ci] -> OIHW [Co][Ci][kd][kh][kw] (accumulate=0 overwrites) */
 int vd_unpack_wgrad(const float* dwp, float* dw_oihw, int Co, int Ci, int kd, int kh, int kw,
                     void* stream);

@@ -377,3 +377,53 @@ def test_stem_im2col_bf16_and_nms_workspace_size():
         torch.cuda.synchronize()
         assert torch.equal(col[..., :27], col32[..., :27].to(torch.bfloat16)) and float(col[..., 27:].abs().max()) == 0.0
     assert L.load().vd_nms_ws_bytes(5, 1000, 400) == 5 * 4
+
+
+@pytest.mark.parametrize("tile", [5, 1, 6, 2, 12, 11])
+@pytest.mark.parametrize("case", [(3, 32, 16, 64), (2, 64, 12, 128), (2, 128, 8, 256), (5, 32, 26, 64)])
+def test_conv_dgrad_stride2_fused_one_launch(case, tile):
+    """VD_CONV_PARITY4 (vd_conv_par.hip): the data gradient of a 3x3 / stride-2 / pad-1 conv as ONE launch - GEMM columns =
+    (parity class, channel), taps = the four offsets of a 2x2 window on dz's grid, zero weight blocks skipped - against the
+    fp64 oracle, accumulating into an existing gradient (residual epilogue), with the fused BatchNorm-backward reductions
+    checked against the same sums taken on the host from the result."""
+    import ctypes as C
+    from viddet_amd import ops, lib as L
+    n, ci, ho, co = case                 # the conv: ci -> co, input 2 ho x 2 ho, output ho x ho
+    h = 2 * ho
+    rng, x, wt = _mk(n, ci, h, h, co, 3, 40 + tile)
+    dy = rng.standard_normal((n, co, ho, ho))
+    prev = rng.standard_normal((n, ci, h, h))
+    dx_ref, _ = R.conv2d_backward(x, wt, dy, 2, 1)
+    wpf = _packed(wt, co)
+    wp4 = torch.empty(4 * ci, 4 * co, device="cuda")
+    mask = ops.pack_weight_dgrad_s2(wpf, wp4, Co=co, Co_pad=co, Ci=ci)
+    assert mask == ops.PARITY4_MASK and bin(mask).count("1") == 9
+    dz = nchw_to_dev_nhwc(dy)
+    dx = nchw_to_dev_nhwc(prev)
+    ds = []
+    ops.conv_dgrad_s2_fused(dz, wp4, dx, Cin=ci, par_mask=mask, residual=dx, tile=tile, desc_out=ds)
+    torch.cuda.synchronize()
+    assert maxdiff(dev_nhwc_to_nchw(dx), dx_ref + prev) < TOL
+    # the same launch carrying the fused BatchNorm-backward reductions of the producer of `x`
+    z = rng.standard_normal((n, ci, h, h))
+    bsc, bsh, bmu, bis = rng.uniform(0.5, 1.5, ci), rng.standard_normal(ci), rng.standard_normal(ci), rng.uniform(0.5, 2.0, ci)
+    d, ax, aw = ds[0]
+    dx2 = nchw_to_dev_nhwc(prev)
+    zd = nchw_to_dev_nhwc(z)
+    vec = [dev(v) for v in (bsc, bsh, bmu, bis)]
+    d.out, d.residual, d.bs_z = dx2.data_ptr(), dx2.data_ptr(), zd.data_ptr()
+    d.bs_scale, d.bs_shift, d.bs_mean, d.bs_invstd = [v.data_ptr() for v in vec]
+    rows = L.load().vd_conv_igemm_mtiles(C.byref(d))
+    part = torch.zeros(rows, 2 * ci, device="cuda")
+    d.bs_part, d.bs_slope = part.data_ptr(), 0.1
+    L.check(L.load().vd_conv_igemm(C.byref(d), L.stream_ptr()), "vd_conv_igemm")
+    torch.cuda.synchronize()
+    g_all = dx_ref + prev
+    assert maxdiff(dev_nhwc_to_nchw(dx2), g_all) < TOL
+    u = z * bsc.reshape(1, -1, 1, 1) + bsh.reshape(1, -1, 1, 1)
+    g = np.where(u > 0, g_all, 0.1 * g_all)
+    s1 = g.sum(axis=(0, 2, 3))
+    s2 = (g * (z - bmu.reshape(1, -1, 1, 1)) * bis.reshape(1, -1, 1, 1)).sum(axis=(0, 2, 3))
+    got = part.double().sum(0).cpu().numpy()
+    tol = 2e-4 * np.sqrt(n * h * h) * 4
+    assert np.abs(got[:ci] - s1).max() < tol and np.abs(got[ci:] - s2).max() < tol * 4

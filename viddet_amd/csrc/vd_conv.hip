@@ -23,6 +23,9 @@
 
 int vd_igemm_sk_dispatch(const vd_conv_desc& d, int tile, hipStream_t s);     // vd_conv_sk.hip
 int vd_igemm_sk_applies(const vd_conv_desc& d, int tile);
+int vd_igemm_par_dispatch(const vd_conv_desc& d, int tile, hipStream_t s);    // vd_conv_par.hip
+int vd_igemm_par_tile(int tile);
+int vd_igemm_par_bm(int tile);
 
 namespace {
 
@@ -672,12 +675,12 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(d->N > 0 && d->Hg > 0 && d->Wg > 0 && d->Co > 0, "vd_conv_igemm: bad shape");
     VD_REQUIRE(check_taps(d->T, d->dy, d->dx, d->Hi, d->Wi), "vd_conv_igemm: bad tap list (T=%d)", d->T);
     VD_REQUIRE(d->Kfr >= 1 && d->Kfr < 128 && d->N % d->Kfr == 0, "vd_conv_igemm: bad Kfr=%d", d->Kfr);
-    VD_REQUIRE(d->ldo >= d->Co, "vd_conv_igemm: ldo < Co");
+    VD_REQUIRE((d->flags & VD_CONV_PARITY4) || d->ldo >= d->Co, "vd_conv_igemm: ldo < Co");
     VD_REQUIRE((int64_t)d->N * d->Hi * d->Wi < (1ll << 31), "vd_conv_igemm: input pixel count overflows int32");
     VD_REQUIRE((int64_t)d->N * d->Hg * d->Wg < (1ll << 31), "vd_conv_igemm: GEMM row count overflows int32");
     VD_REQUIRE((d->Hg - 1) * d->out_stride + d->out_oy < d->Ho && (d->Wg - 1) * d->out_stride + d->out_ox < d->Wo,
                "vd_conv_igemm: output grid exceeds output tensor");
-    VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm: residual missing");
+    VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && (d->ldr >= d->Co || (d->flags & VD_CONV_PARITY4))), "vd_conv_igemm: residual missing");
     VD_REQUIRE((d->in_scale == nullptr) == (d->in_shift == nullptr), "vd_conv_igemm: in_scale/in_shift mismatch");
     VD_REQUIRE(!d->stats_part || (d->flags & 7) == 0, "vd_conv_igemm: fused BN statistics need a raw (epilogue-free) output");
     // (any output geometry: a stride-2 data gradient is four parity launches, each adding its own rows to the partial table)
@@ -688,6 +691,22 @@ int vd_conv_igemm(const vd_conv_desc* d, void* stream) {
     VD_REQUIRE(!(d->flags & VD_MATH_F16X2) || (d->amax_in && d->amax_w && !d->in_scale),
                "vd_conv_igemm: VD_MATH_F16X2 needs amax_in and amax_w (and no in-load transform)");
     hipStream_t s = (hipStream_t)stream;
+    if (d->flags & VD_CONV_PARITY4) {
+        VD_REQUIRE((d->flags & VD_MATH_F16X2) && !(d->flags & (VD_EPI_AFFINE | VD_EPI_LEAKY)) && !d->stats_part && !d->in_scale,
+                   "vd_conv_igemm: VD_CONV_PARITY4 runs in VD_MATH_F16X2 with a residual / bs_* epilogue only");
+        VD_REQUIRE(d->T == 4 && d->dy[0] == 0 && d->dx[0] == 0 && d->dy[1] == 0 && d->dx[1] == 1 && d->dy[2] == 1 && d->dx[2] == 0 &&
+                   d->dy[3] == 1 && d->dx[3] == 1 && d->in_stride == 1 && d->Hg == d->Hi && d->Wg == d->Wi && d->Kfr == 1,
+                   "vd_conv_igemm: VD_CONV_PARITY4 taps are the offsets (0,0) (0,1) (1,0) (1,1) on the gradient's own grid");
+        VD_REQUIRE(d->out_stride == 2 && d->Ho == 2 * d->Hg && d->Wo == 2 * d->Wg && d->par_cin >= 32 && d->par_cin % 32 == 0 &&
+                   d->Co == 4 * d->par_cin && d->ldo >= d->par_cin && d->ldo % 4 == 0 && (uintptr_t)d->out % 16 == 0 &&
+                   (!(d->flags & VD_EPI_RESIDUAL) || (d->ldr % 4 == 0 && (uintptr_t)d->residual % 16 == 0)),
+                   "vd_conv_igemm: VD_CONV_PARITY4 geometry (even output, Co = 4 par_cin, aligned rows)");
+        VD_REQUIRE(!d->bs_part || (((uintptr_t)d->bs_z | (uintptr_t)d->bs_scale | (uintptr_t)d->bs_shift | (uintptr_t)d->bs_mean |
+                                    (uintptr_t)d->bs_invstd) % 16 == 0), "vd_conv_igemm: VD_CONV_PARITY4 bs_* alignment");
+        vd_igemm_par_dispatch(*d, vd_igemm_par_tile(d->tile), s);
+        VD_CHECK_LAUNCH("vd_conv_igemm/parity4");
+        return VD_OK;
+    }
     if (d->in_scale) dispatch_igemm<true>(*d, s);
     else dispatch_igemm<false>(*d, s);
     VD_CHECK_LAUNCH("vd_conv_igemm");
@@ -707,6 +726,8 @@ int64_t vd_conv_igemm_streamk_ws_bytes(void) {
 int vd_conv_igemm_mtiles(const vd_conv_desc* d) {
     if (!d) return 0;
     const int64_t M = (int64_t)d->N * d->Hg * d->Wg;
+    if (d->flags & VD_CONV_PARITY4)           // one table row per (M tile, column tile): columns of 128
+        return (int)(vd_cdiv(M, vd_igemm_par_bm(vd_igemm_par_tile(d->tile))) * vd_cdiv(d->Co, 128));
     if (d->flags & (VD_MATH_SPLIT | VD_MATH_BF16 | VD_MATH_F16X2)) return (int)vd_cdiv(M, igemm_split_tile_bm(igemm_split_resolve_tile(*d)));
     return (int)vd_cdiv(M, igemm_tile_bm(igemm_resolve_tile(*d)));
 }

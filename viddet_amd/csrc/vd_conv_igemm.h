@@ -194,10 +194,18 @@ struct RowInfo {
 // previous workgroup left - the same MFMA chain in the same order as an uncut tile, so every output is bit-identical to the
 // one-workgroup-per-tile kernel's (nothing is summed across the seam).  The hand-off is needed a whole run after it was
 // published; a bounded poll that gives up recomputes the prefix itself, so no dispatch order can hang the grid.
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3, bool HALO = false, bool SK = false>
+// PAR (NPL == 2, generic loop; vd_conv_par.hip): the data gradient of a 3x3 / stride-2 / pad-1 convolution as ONE launch
+// (VD_CONV_PARITY4, include/viddet_hip.h).  GEMM rows are the positions q of the incoming gradient's grid, GEMM columns
+// the four output parity classes x Cin (column block c = class (py, px) = (c >> 1, c & 1), output pixel (2 qy + py,
+// 2 qx + px)), taps the four offsets {0, 1}^2 of a 2x2 window: the nine (class, kernel tap) pairs of the four parity
+// launches it replaces are nine of the sixteen (offset, class) weight blocks, the other seven are zero and their MFMAs are
+// skipped (wave-uniform test per 32-column block and K-step).  One gather and one LDS stage of dz instead of four.
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16 = false, bool BS = false, int NPL = 3, bool HALO = false, bool SK = false,
+          bool PAR = false>
 __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && WM * WN == 4) ? 2 : 1))) void k_conv_igemm(const vd_conv_desc p, const int64_t zd_in, const int64_t zd_w, const int sk_lds_flag, const int sk_timeout) {
     static_assert(NPL == 3 || ((NPL == 1 || NPL == 2) && SP), "planes");
     static_assert(!SK || (NPL == 2 && VD_KORDER && !VD_KROT && !XF), "stream-K: the fp16-split tiles, taps-innermost K order");
+    static_assert(!PAR || (NPL == 2 && !HALO && !SK && VD_KORDER && !VD_KROT), "parity-fused data gradient: fp16-split tiles, generic loop");
     static_assert(NPL != 2 || !XF, "the fp16 split needs the max-abs of the operand it splits: no in-load transform");
     static_assert(!HALO || (NPL == 2 && WM * WN == 8 && WN * TN * 32 >= 64), "the halo loop exists for the 8-wave fp16-split tiles");
     constexpr int SP_ROWB = NPL * 64;          // LDS row of the split arithmetic: NPL planes of 32 bf16 (fp16 for NPL == 2)
@@ -532,7 +540,23 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
         for (int i = 0; i < BP; ++i)
             *reinterpret_cast<f32x4*>(b + (lrow + RPP * i) * LDS_LD + lc4) = rb[i];
     };
+    // PAR: tap (offset) of the K-step about to be multiplied, and the 16 (offset, class) bits of the nonzero weight blocks
+    int ctap = 0;
+    const unsigned par_mask = PAR ? (unsigned)p.par_mask : 0xffffu;
+    const int par_col0 = tile_n * BN + wn * TN * 32;              // first column of this wave
+    auto par_nz = [&](int col) -> bool {                          // is the block of column `col` nonzero for tap ctap?
+        return !PAR || ((par_mask >> (ctap * 4 + col / p.par_cin)) & 1u);
+    };
     auto compute = [&](int buf) {
+        if (PAR) {
+            bool any = false;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) any = any || par_nz(par_col0 + ni * 32);
+            if (!any) {                                           // every block of this wave's columns is zero for this offset
+                if (++ctap >= 4) ctap = 0;
+                return;
+            }
+        }
         if (SP && M16) {
             const int r16 = lane & 15, ch = lane >> 4;              // operand row within a 16-row block, 8-k chunk
             const int rkey = NPL == 2 ? f16x2_key<M16>(r16) : 2 * ((r16 >> 3) & 1);
@@ -548,6 +572,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
                     fa[mb][q] = *reinterpret_cast<const v4i*>(a3 + mb * 16 * SP_ROWB + slot(q));
 #pragma unroll
             for (int nb = 0; nb < 2 * TN; ++nb) {
+                if (PAR && !par_nz(par_col0 + nb * 16)) continue;
                 v4i fb[NPL];
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) fb[q] = *reinterpret_cast<const v4i*>(b3 + nb * 16 * SP_ROWB + slot(q));
@@ -568,6 +593,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
+            if (PAR) { if (++ctap >= 4) ctap = 0; }
             return;
         }
         if (SP) {
@@ -596,12 +622,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
+                        for (int ni = 0; ni < TN; ++ni) {
+                            if (PAR && !par_nz(par_col0 + ni * 32)) continue;
                             acc[mi][ni] = mfma32<NPL>(fa[mi][Terms<NPL>::QA[t]], fb[ni][Terms<NPL>::QB[t]], acc[mi][ni]);
+                        }
 #if VD_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
+            if (PAR) { if (++ctap >= 4) ctap = 0; }
             return;
         }
         const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
@@ -1013,8 +1042,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int col = tile_n * BN + wn * TN * 32 + ni * 32 + ec4;
-            colv[ni] = col < p.Co ? col : -1;
-            const int cc = col < p.Co ? col : 0;
+            // (PAR: GEMM column = class * Cin + channel; everything below addresses by the channel)
+            const int chn = PAR ? col % p.par_cin : col;
+            colv[ni] = col < p.Co ? chn : -1;
+            const int cc = col < p.Co ? chn : 0;
             sc[ni] = (has_aff && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + cc) : ones;
             sh[ni] = (has_aff && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + cc) : zeros;
             if (BS) {
@@ -1031,18 +1062,21 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
         int64_t ropix[NSL][4];
         auto issue = [&](int mi, int ni, f32x4 (&rr)[4], f32x4 (&zz)[4], int64_t (&op)[4]) {
             const int cc = colv[ni] < 0 ? 0 : colv[ni];
+            // PAR: the parity class of this 32-column block picks the output pixel of a row
+            const int pcls = PAR ? (tile_n * BN + wn * TN * 32 + ni * 32) / p.par_cin : 0;
+            const int o_y = PAR ? (pcls >> 1) : p.out_oy, o_x = PAR ? (pcls & 1) : p.out_ox;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int64_t m = (int64_t)tile_m * BM + wm * TM * 32 + mi * 32 + erow + 8 * i;
                 m = m < M ? m : M - 1;
                 int64_t opix = m;
-                if (!direct) {
+                if (PAR || !direct) {
                     const unsigned mu = (unsigned)m;
                     const unsigned t = udiv_rcp(mu, (unsigned)p.Wg, rcp_w);
                     const int gx = (int)(mu - t * (unsigned)p.Wg);
                     const unsigned n = udiv_rcp(t, (unsigned)p.Hg, rcp_h);
                     const int gy = (int)(t - n * (unsigned)p.Hg);
-                    opix = ((int64_t)n * p.Ho + (gy * p.out_stride + p.out_oy)) * p.Wo + (gx * p.out_stride + p.out_ox);
+                    opix = ((int64_t)n * p.Ho + (gy * p.out_stride + o_y)) * p.Wo + (gx * p.out_stride + o_x);
                 }
                 op[i] = opix;
                 if (has_res) rr[i] = *reinterpret_cast<const f32x4*>(p.residual + opix * p.ldr + cc);
@@ -1214,6 +1248,27 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
                 }
             }
         __syncthreads();
+        if (PAR) {
+            // columns of different parity classes are the same CHANNEL: one table row [2 Cin] per (tile_m, tile_n), the
+            // classes a tile holds folded into it; rows of tiles narrower than Cin fill their own channels only (the host
+            // zeroes the table first).  vd_conv_igemm_mtiles() counts these rows.
+            const int cin = p.par_cin, ncls = BN > cin ? BN / cin : 1, nch = BN < cin ? BN : cin;
+            float* dstp = p.bs_part + ((int64_t)tile_m * ntile + tile_n) * 2 * cin;
+            for (int c = tid; c < nch; c += NT) {
+                if (tile_n * BN + c < p.Co) {
+                    float a = 0.f, b = 0.f;
+                    for (int j = 0; j < ncls; ++j)
+#pragma unroll
+                        for (int w = 0; w < WM; ++w) {
+                            a += red[(w * BN + c + j * cin) * 2 + 0];
+                            b += red[(w * BN + c + j * cin) * 2 + 1];
+                        }
+                    const int ch = (tile_n * BN + c) % cin;
+                    dstp[ch] = a;
+                    dstp[cin + ch] = b;
+                }
+            }
+        } else {
         for (int c = tid; c < BN; c += NT) {
             const int colc = tile_n * BN + c;
             if (colc < p.Co) {
@@ -1227,6 +1282,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
                 dstp[colc] = a;
                 dstp[p.Co + colc] = b;
             }
+        }
         }
     }
 
@@ -1314,7 +1370,7 @@ const float* zero_page() {
     return zp;
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO = false, bool SK = false>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO = false, bool SK = false, bool PAR = false>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s);
 
 // LDS bytes of the halo loop for a BM x BN tile on a map of width W: two halo buffers of BM + 2 (W + 1) rows (+ zero row
@@ -1382,7 +1438,7 @@ inline int streamk_grid(const vd_conv_desc& d, int BM, int BN, int wg_per_cu) {
     return G;
 }
 
-template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO, bool SK>
+template <int WM, int WN, int TM, int TN, bool XF, bool SP, bool M16, bool BS, int NPL, bool HALO, bool SK, bool PAR>
 int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds0 = SP ? 2 * (BM + BN) * NPL * 64 : 2 * (BM + BN) * LDS_LD * (int)sizeof(float);
@@ -1406,7 +1462,7 @@ int launch_igemm_bs(const vd_conv_desc& d, hipStream_t s) {
         nblk = G;
     }
     static bool attr_done = false;
-    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS, NPL, HALO, SK>;
+    auto kfn = k_conv_igemm<WM, WN, TM, TN, XF, SP, M16, BS, NPL, HALO, SK, PAR>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   HALO ? 160 * 1024 : lds_fixed + (SK ? 16 : 0));

@@ -20,6 +20,7 @@ MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-sta
 STORE_BF16 = 256       # vd_wgrad_desc.flags: `in` / `dout` are bf16 tensors (bf16-storage training)
 WGRAD_HALO = 512       # vd_wgrad_desc.flags: halo-ring kernel for 3x3 / stride-1 weight gradients (vd_wgrad_halo.hip)
 CONV_STREAMK = 1024    # vd_conv_desc.flags: persistent stream-K grid (vd_conv_sk.hip); bit-identical results
+CONV_PARITY4 = 2048    # vd_conv_desc.flags: a 3x3 / stride-2 data gradient as ONE launch (vd_conv_par.hip)
 SK_HEADER_BYTES = 16384
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
@@ -43,6 +44,7 @@ class ConvDesc(C.Structure):
         ("bs_slope", C.c_float),
         ("amax_in", _fp), ("amax_w", _fp), ("amax_out", _fp),
         ("sk_ws", _fp), ("sk_ws_bytes", C.c_int64),
+        ("par_cin", C.c_int32), ("par_mask", C.c_int32),
     ]
 
 
@@ -93,6 +95,7 @@ SIGNATURES = {
     "vd_stem_im2col": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_pack_weight_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vd_pack_weight_dgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _i, _p]),
+    "vd_pack_weight_dgrad_s2": (_i, [_p, _p, _i, _i, _i, C.POINTER(C.c_int32), _p]),
     "vd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vd_bn_stats_ws_bytes": (_i64, [_i64, _i]),
     "vd_bn_stats": (_i, [_p, _i64, _i, _p, _p, _i64, _p]),

@@ -336,6 +336,8 @@ def set_conv_math(mode):
 def _tile_candidates(d, math):
     """(flags bit, tile) candidates of one launch record."""
     import os
+    if d.flags & L.CONV_PARITY4:            # the parity-fused stride-2 data gradient: fp16 split, the tiles it is built for
+        return [(L.MATH_F16X2, t) for t in (5, 1, 6, 2, 12, 11)]
     cands = []
     if math in ("native", "auto"):
         if d.Co <= 32:
@@ -2101,6 +2103,55 @@ class YOLOV3(object):
             fuse_m = pm if (self.fuse_bn_bwd and pm is not None and (len(plans) == 1 or (n.kd == 1 and _fuse_bwd_s2())) and
                             consumers[n.src][0] is n and pm.fr == n.fr) else None
             bs_rows = 0
+            # ---- a 3x3 / stride-2 data gradient as ONE launch (VD_CONV_PARITY4, vd_conv_par.hip) instead of four parity
+            # launches that each gather and stage the whole dz: rows = positions of dz's grid, columns = (parity class,
+            # channel), taps = the four offsets of a 2x2 window, zero (offset, class) weight blocks skipped.
+            # VD_S2_FUSED=0 keeps the four launches (also: odd maps, other arithmetics, range-exact operands, pinned kernels).
+            import os as _os
+            fused_s2 = (len(plans) == 4 and n.k == 3 and n.stride == 2 and n.pad == 1 and n.kd == 1 and Hi % 2 == 0 and Wi % 2 == 0 and
+                        _os.environ.get('VD_S2_FUSED', '1') == '1' and n.cin % 32 == 0 and
+                        # (measured per layer, batch 64 / 416x416, four launches -> one: 32 channels 1.51 -> 1.12 ms, 64: 0.80 ->
+                        # 0.80, 128: 0.55 -> 0.66, 256: 0.53 -> 0.59, 512: 0.47 -> 0.53 - the one launch stages all sixteen
+                        # (offset, class) weight blocks for nine useful ones, which only pays where a parity launch has too few
+                        # output channels to fill a tile; VD_S2_FUSED_MAX_CIN moves the limit)
+                        n.cin <= int(_os.environ.get('VD_S2_FUSED_MAX_CIN', '64')) and
+                        self._amax_or_none(bufs, 'dz:' + n.name) is not None and
+                        (fp32_math() == 'split2' or (fp32_math() == 'auto' and _os.environ.get('VD_AUTOTUNE', '1') != '0')))
+            if fused_s2:
+                wp4 = torch.empty(16 * n.cin * n.co_pad, device=dev)
+                dgrad_packs.append((n, dict(fused_s2=True), wp4))
+                d = ConvDesc()
+                d.in_, d.wp, d.out = dz.data_ptr(), wp4.data_ptr(), dsrc.data_ptr()
+                d.N, d.Hi, d.Wi, d.Ci = B * n.fr, Ho, Wo, n.co_pad
+                d.Hg, d.Wg, d.in_stride = Ho, Wo, 1
+                ops._set_taps(d, ops.PARITY4_TAPS)
+                d.Kfr, d.Ho, d.Wo, d.Co = 1, Hi, Wi, 4 * n.cin
+                d.out_stride, d.out_oy, d.out_ox = 2, 0, 0
+                d.ldo = d.ldr = n.cin
+                d.par_cin, d.par_mask = n.cin, ops.PARITY4_MASK   # (offset, class) blocks that hold a kernel tap
+                d.flags, d.slope = (EPI_RESIDUAL if acc else 0) | L.MATH_F16X2 | L.CONV_PARITY4, LEAKY_SLOPE
+                d.amax_in, d.amax_w = self._amax_or_none(bufs, 'dz:' + n.name), n.wamax.data_ptr()
+                if acc:
+                    d.residual = res_src.data_ptr()
+                seg.hold(d, wp4)
+                if fuse_m is not None:
+                    d.bs_z = bufs['z:' + fuse_m.dst].data_ptr()
+                    d.bs_scale, d.bs_shift = fuse_m.b_scale.data_ptr(), fuse_m.b_shift.data_ptr()
+                    d.bs_mean, d.bs_invstd = fuse_m.b_mean.data_ptr(), fuse_m.b_invstd.data_ptr()
+                    d.bs_part, d.bs_slope = stats_ws.data_ptr(), LEAKY_SLOPE
+                autotune_desc(d)                                   # fixes the tile, hence the rows of the partial table
+                if fuse_m is not None:
+                    mt = L.load().vd_conv_igemm_mtiles(C.byref(d))
+                    assert mt * 2 * fuse_m.cout * 4 <= stats_ws.numel() * 4, "stats workspace too small"
+                    seg.add('vd_fill', stats_ws.data_ptr(), 0.0, mt * 2 * fuse_m.cout)     # column tiles narrower than Cin fill part of a row
+                seg.add('vd_conv_igemm', C.byref(d), meta=dict(
+                    kind='dgrad', node=n.name, k=n.k, stride=n.stride, fused_s2=True,
+                    flops=2.0 * n.cin * n.cout * 9 * Ho * Wo * B * n.fr, bytes=self._flops(n, B, H, W, 'dgrad')['bytes']))
+                if fuse_m is not None:
+                    seg.add('vd_bn_sum_param_grads', stats_ws.data_ptr(), mt, fuse_m.cout, fuse_m.sums2.data_ptr(),
+                            fuse_m.ggamma.data_ptr(), fuse_m.gbeta.data_ptr(), ws.data_ptr(), ws_bytes)
+                    fused_bwd.add(fuse_m.name)
+                continue
             # Frame chunks of a stride-2 data gradient (VD_S2_CHUNK_MB > 0; default 0 = one launch per parity class): each of
             # the four parity launches streams the WHOLE incoming gradient dz - 709 MB at 208 x 208 x 64 channels, batch 64 - and
             # is HBM-bound on it (isolated: 5.9 TB/s on the one-tap class).  Cut into chunks of frames whose dz fits the 256 MB
@@ -2620,16 +2671,22 @@ class YOLOV3(object):
             self._pack_stream.wait_stream(cur)          # the optimiser's weight update is on the main stream
             with torch.cuda.stream(self._pack_stream):
                 for n, plan, wpk in tp['dgrad_packs']:
-                    ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
-                                          tap_ids=plan['tap_ids'], src_packed=True)
+                    self._pack_dgrad(n, plan, wpk)
                 ev = torch.cuda.Event()
                 ev.record(self._pack_stream)
         else:
             for n, plan, wpk in tp['dgrad_packs']:
-                ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
-                                      tap_ids=plan['tap_ids'], src_packed=True)
+                self._pack_dgrad(n, plan, wpk)
         self._pack_event = ev
         tp['dgrad_version'] = self._weights_version
+
+    @staticmethod
+    def _pack_dgrad(n, plan, wpk):
+        if plan.get('fused_s2'):            # the one-launch form of a stride-2 data gradient (VD_CONV_PARITY4)
+            ops.pack_weight_dgrad_s2(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin)
+        else:
+            ops.pack_weight_dgrad(n.wp, wpk, Co=n.co_pad, Co_pad=n.co_pad, Ci=n.cin, kd=n.kd, kh=n.k, kw=n.k,
+                                  tap_ids=plan['tap_ids'], src_packed=True)
 
     @staticmethod
     def _run_segments(segs):

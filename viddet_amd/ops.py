@@ -242,6 +242,52 @@ def pack_weight_dgrad(w, wp, *, Co, Co_pad, Ci, kd, kh, kw, tap_ids, src_packed)
                                       1 if src_packed else 0, _s()), "vd_pack_weight_dgrad")
 
 
+PARITY4_TAPS = [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)]
+
+
+def _parity4_mask():
+    """bit (4 * offset + class) set where a 3x3 / stride-2 / pad-1 kernel has a tap for output parity class c = 2 py + px at
+    gradient offset o = 2 dy + dx (vd_conv_par.hip par_tap: parity 0 -> k = 1 at offset 0; parity 1 -> k = 2 at 0, k = 0 at 1)"""
+    tap = lambda parity, off: (1 if off == 0 else -1) if parity == 0 else (2 if off == 0 else 0)
+    m = 0
+    for o in range(4):
+        for c in range(4):
+            if tap(c >> 1, o >> 1) >= 0 and tap(c & 1, o & 1) >= 0:
+                m |= 1 << (4 * o + c)
+    return m
+
+
+PARITY4_MASK = _parity4_mask()          # 0x8caf: nine of the sixteen blocks
+
+
+def pack_weight_dgrad_s2(wp_fwd, wp4, *, Co, Co_pad, Ci):
+    """weight image of the parity-fused stride-2 data gradient (VD_CONV_PARITY4): fwd-packed [Co][9 * Ci] ->
+    [4 * Ci][4 * Co_pad]; returns the 16-bit mask of its nonzero (offset, class) blocks"""
+    m = C.c_int32(0)
+    check(_lib().vd_pack_weight_dgrad_s2(ptr(wp_fwd), ptr(wp4), Co, Co_pad, Ci, C.byref(m), _s()), "vd_pack_weight_dgrad_s2")
+    return int(m.value)
+
+
+def conv_dgrad_s2_fused(dz, wp4, dx, *, Cin, par_mask, residual=None, tile=0, amax_in=None, amax_w=None, desc_out=None):
+    """dx [N, 2 Ho, 2 Wo, Cin] = data gradient of a 3x3 / stride-2 / pad-1 conv from dz [N, Ho, Wo, Cout] in ONE launch"""
+    N, Ho, Wo, Cout = dz.shape
+    d = ConvDesc()
+    d.tile = tile
+    d.in_, d.wp, d.out, d.residual = ptr(dz), ptr(wp4), ptr(dx), ptr(residual)
+    d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = N, Ho, Wo, Cout, Ho, Wo, 1
+    _set_taps(d, PARITY4_TAPS)
+    d.Kfr, d.Ho, d.Wo, d.Co = 1, 2 * Ho, 2 * Wo, 4 * Cin
+    d.out_stride, d.out_oy, d.out_ox, d.ldo, d.ldr = 2, 0, 0, dx.shape[-1], dx.shape[-1]
+    d.flags = MATH_F16X2 | L.CONV_PARITY4 | (EPI_RESIDUAL if residual is not None else 0)
+    d.par_cin, d.par_mask, d.slope = Cin, par_mask, 0.1
+    amax_in = amax(dz) if amax_in is None else amax_in
+    amax_w = amax(wp4) if amax_w is None else amax_w
+    d.amax_in, d.amax_w = ptr(amax_in), ptr(amax_w)
+    if desc_out is not None:
+        desc_out.append((d, amax_in, amax_w))
+    check(_lib().vd_conv_igemm(C.byref(d), _s()), "vd_conv_igemm/parity4")
+
+
 def unpack_weight(wp, w_oihw):
     """fwd-packed [>=Co][T*Ci] -> OIHW (also used for gradients)."""
     Co, Ci = w_oihw.shape[0], w_oihw.shape[1]
