@@ -343,7 +343,11 @@ def main():
         # launches the plan runs as persistent stream-K grids (VD_CONV_STREAMK: bit-identical results, another cut of the
         # launch into workgroups; the autotuner takes the form per launch record where it is faster)
         sk_recs = [(m, e0.elapsed_time(e1)) for f_, m, e0, e1 in recs if f_ == "vd_conv_igemm" and m.get("streamk")]
-        roof["streamk"] = {"launches": len(sk_recs), "ms": round(sum(t for _, t in sk_recs), 3),
+        # hand-off polls that gave up (the consumer then recomputes its tile's K-prefix: correct, wasted work) over the whole
+        # run so far, all workspaces: warm-up + timed steps + the diagnostic replays - beside a side stream's long-lived
+        # weight-gradient workgroups a persistent grid is not always resident at once
+        gave_up = sum(int(w.view(torch.int32)[2047]) for w in getattr(net, "_sk_ws", {}).values())
+        roof["streamk"] = {"launches": len(sk_recs), "ms": round(sum(t for _, t in sk_recs), 3), "polls_given_up_total": gave_up,
                            "tflops": round(sum(m["flops"] for m, _ in sk_recs) / max(1e-9, sum(t for _, t in sk_recs)) / 1e9, 2) if sk_recs else None,
                            "switch": "VD_STREAMK=%s" % os.environ.get("VD_STREAMK", "1")}
         if math is not None:

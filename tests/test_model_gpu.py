@@ -335,8 +335,7 @@ def test_data_parallel_two_ranks_equal_one_process():
     # all-reduce: duplicate shards bit-identical over two steps, real shards within the bf16 tolerance
     for extra in (dict(VD_DP_DUP="1"), dict(), dict(VD_DP_DUP="1", VD_DP_K="3", VD_DP_SCOPE="reference"),
                   dict(VD_DP_K="3"), dict(VD_DP_DUP="1", VD_DP_STEPS="3"),
-                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_STEPS="2"), dict(VD_DP_STORAGE="bf16"),
-                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_SCOPE="reference")):
+                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_STEPS="2"), dict(VD_DP_STORAGE="bf16")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
                            text=True, timeout=600, env=dict(base, **extra))
         assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (extra, r.stdout[-800:], r.stderr[-1500:])

@@ -147,7 +147,9 @@ class TuneCache(dict):
         here = os.path.dirname(os.path.abspath(__file__))
         # the conv kernels' sources (the public header is not part of it: declarations of other entry points change there
         # without touching a tile; descriptor layouts are guarded by the ABI revision)
-        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_bf16.hip", "vd_wgrad_halo.hip", "vd_common.h")]
+        srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_igemm.h", "vd_conv_sk.hip", "vd_conv_par.hip",
+                                                         "vd_conv_bf16.hip", "vd_conv_igemm_bf16.h", "vd_conv_bf16_sk.hip",
+                                                         "vd_wgrad_halo.hip", "vd_common.h")]
         h = hashlib.sha256()
         if all(os.path.exists(f) for f in srcs):
             for f in srcs:
