@@ -104,9 +104,6 @@ class Program:
                     meta = dict(meta or {}, split=bool(d.flags & L.MATH_SPLIT), bf16=bool(d.flags & L.MATH_BF16),
                                 f16x2=bool(d.flags & L.MATH_F16X2), nohalo=bool(d.flags & L.MATH_NOHALO), tile=int(getattr(d, "tile", 0)),
                                 streamk=bool(fname == "vd_conv_igemm" and L.load().vd_conv_igemm_streamk(args[0])))
-                if fname == "vd_conv_igemm_bf16":
-                    meta = dict(meta or {}, tile=int(args[0]._obj.tile), nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO),
-                                streamk=bool(L.load().vd_conv_igemm_bf16_streamk(args[0], args[1])))
                     if fname == "vd_conv_wgrad":                # the halo-ring kernel (vd_wgrad_halo.hip) or the generic one
                         meta["wgrad_halo"] = bool(L.load().vd_conv_wgrad_uses_halo(args[0]))
                     if fname == "vd_conv_igemm" and meta.get("bytes"):
@@ -116,6 +113,9 @@ class Program:
                         extra = (out_bytes if d.residual else 0.0) + (out_bytes if getattr(d, "bs_part", None) else 0.0)
                         meta["bytes_epilogue_reads"] = extra
                         meta["bytes"] = meta["bytes"] + extra
+                if fname == "vd_conv_igemm_bf16":
+                    meta = dict(meta or {}, tile=int(args[0]._obj.tile), nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO),
+                                streamk=bool(L.load().vd_conv_igemm_bf16_streamk(args[0], args[1])))
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
