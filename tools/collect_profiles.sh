@@ -13,7 +13,7 @@ cp $O/train_cfg4_bf16products_bench.json $P/${T}_train_cfg4_b32_608_c285_bf16pro
 cp $O/train_cfg4_bf16storage_last_step_kernels.json $P/${T}_train_cfg4_bf16storage_last_step_kernels.json
 cp $O/second_start.time $P/${T}_second_start_seconds.txt
 # the tuning table of this library build (keyed by the kernel-source hash): read by every later start
-mkdir -p viddet_amd/tune && python - <<PY
+[ -f $O/tune_table.json ] && mkdir -p viddet_amd/tune && python - <<PY
 import json, shutil
 from viddet_amd.model import TuneCache
 doc = json.load(open("$O/tune_table.json"))

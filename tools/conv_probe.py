@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Time ONE forward conv shape (events, median of several launches) — used with VD_IGEMM_PROBE timing probes.
-usage: conv_probe.py cin cout k stride hin [tile] [split: 0 | 1 | f16x2 | f16x2nh | bf16] [batch]"""
+usage: conv_probe.py cin cout k stride hin [tile] [split: 0 | 1 | f16x2 | f16x2nh | bf16] [batch]
+VD_PROBE_STREAMK=1: the persistent stream-K form of the launch (fp16 split only)"""
 import os
 import sys
 
@@ -21,15 +22,16 @@ w = torch.zeros(cout, cin, k, k, device="cuda") if zero else torch.randn(cout, c
 wp = torch.empty(cout, k * k * cin, device="cuda")
 ops.pack_weight_fwd(w, wp, cout)
 y = torch.empty(B, ho, ho, cout, device="cuda")
+skws = ops.streamk_workspace() if os.environ.get("VD_PROBE_STREAMK") == "1" else None
 ts = []
 for i in range(12):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=tile, split=split)
+    ops.conv_fwd(x, wp, y, k=k, stride=s, pad=pad, Co=cout, tile=tile, split=split, streamk_ws=skws)
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ts = sorted(ts[2:])
 t = ts[len(ts) // 2]
-print("lib=%s tile=%d split=%s  %.3f ms  %.1f TFLOP/s" % (os.path.basename(os.environ.get("VD_LIB", "default")), tile, split, t,
+print("lib=%s tile=%d split=%s streamk=%s  %.3f ms  %.1f TFLOP/s" % (os.path.basename(os.environ.get("VD_LIB", "default")), tile, split, skws is not None, t,
                                                         2.0 * cin * cout * k * k * ho * ho * B / t / 1e9))

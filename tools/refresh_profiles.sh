@@ -2,7 +2,8 @@ set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${VD_PROFILE_TAG:-r01j}; mkdir -p $O
 cd $R
 # every bench of this run reads / extends ONE tuning table: copied into viddet_amd/tune/ afterwards (tools/collect_profiles.sh)
-export VD_TUNE_CACHE=$O/tune_table.json
+# (VD_PROFILE_KEEP_TABLE=1: run on the committed table under viddet_amd/tune/ instead - the kernels the driver's run takes)
+if [ "${VD_PROFILE_KEEP_TABLE:-0}" != "1" ]; then export VD_TUNE_CACHE=$O/tune_table.json; fi
 python bench.py > $O/train_bench.json 2> $O/train_bench.err
 echo "train done"; cut -c1-160 $O/train_bench.json
 python bench.py --mode detect --no-cpu-baseline > $O/detect_bench.json 2> $O/detect.err
