@@ -301,7 +301,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((!SP && WM * WN == 8) ? 4 : ((SP && 
         else if (sk_it - (hasA ? 1 : 0) < sk_nwhole) lid = sk_t0 + sk_it - (hasA ? 1 : 0);
         else { lid = sk_tfirst; kb = sk_brem; sk_mode = 2; }
     }
-    const int tile_n = lid % ntile, tile_m = lid / ntile;
+    // Tile order.  One workgroup per tile: column tiles fastest, so that the workgroups an XCD runs together (consecutive ids
+    // after the XCD remap) share activation rows AND weight columns in its L2.  SK: a workgroup walks its run of tiles alone
+    // and its XCD neighbours are a whole run apart, so the order that shares operands is the other one - row tiles
+    // fastest: the workgroups of a group then sit in the same one or two column tiles and stream ONE weight panel through
+    // their L2 (the first build, column tiles fastest, fetched 570 MB per launch of 256 -> 512 @26 where the one-tile
+    // form fetches 162: PMC, profiles/r04_pmc_mfma_streamk.txt).
+    const int mt_all = (int)vd_cdiv(M, BM);
+    const int tile_n = SK ? lid / mt_all : lid % ntile, tile_m = SK ? lid % mt_all : lid / ntile;
     RowInfo ri[AP];
     {
         int riy[AP], rix[AP], rfz[AP];
