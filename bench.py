@@ -275,13 +275,17 @@ def main():
                                           frac_of_hbm_peak=round(head_bytes / ms / 1e6 / 8000.0, 4))
                     else:
                         cand = float(net._programs[("infer_bf16" if a.dtype == "bf16" else "infer", B, S, S)][2]["counts"].float().sum())
-                        extra[key].update(candidates=int(cand), note="one workgroup per image: radix select of the top 400, "
-                                          "bitonic sort, 400 x 400 IoU bitmask, sweep; reads 8 B per candidate (%.2f MB) - "
-                                          "latency-bound, not an HBM kernel" % (8.0 * cand / 1e6))
+                        extra[key].update(candidates=int(cand), note="one workgroup (one CU) per image: radix select of the top 400 "
+                                          "(12 + 12 + 8 bit digits), bitonic sort, 400 x 400 IoU bitmask by ballots, chunked sweep; "
+                                          "reads 8 B per candidate (%.2f MB) - bound by one CU's issue rate, not an HBM kernel; "
+                                          "phases: tools/nms_probe.sh" % (8.0 * cand / 1e6))
             if "decode_filter" in extra and "nms" in extra:
                 t = extra["decode_filter"]["ms"] + extra["nms"]["ms"]
                 extra["decode_plus_nms"] = {"ms": round(t, 4), "gb_s": round((head_bytes + B * K * 2400.0) / t / 1e6, 1),
                                             "algorithmic_mb_per_frame": round((head_bytes / (B * K) + 2400.0) / 1e6, 3)}
+            nsplit = sum(1 for (f_, m, e0, e1) in recs if f_ == "vd_conv_igemm_bf16" and m and m.get("splitk"))
+            if nsplit:
+                extra["splitk_launches"] = nsplit       # VD_CONV_SPLITK: launches with too few tiles for the chip, cut along K
             recs = [("vd_conv_igemm", m, e0, e1) for (f_, m, e0, e1) in recs if f_ in ("vd_conv_igemm", "vd_conv_igemm_bf16")]
         torch.cuda.synchronize()
         # the stand-alone forward BatchNorm+LeakyReLU passes, and the part of them that belongs to cells whose output feeds

@@ -88,8 +88,17 @@ extern "C" {
  * nonzero (vd_pack_weight_dgrad_s2 returns it).  Replaces autograd's backward of nn.Conv2D(strides=2),
  * three_darknet.py:182-183. */
 #define VD_CONV_PARITY4  2048
+/* vd_conv_igemm_bf16 only: SPLIT-K for launches whose tiles cannot fill the chip (batch-1 detection: 24 tiles of 128 x 128
+ * at 19 x 19).  Each tile is cut along K into 2..8 parts run by as many workgroups; every part publishes its raw
+ * accumulators in `sk_ws` (the stream-K workspace and hand-off protocol) and the part that arrives LAST sums them in part
+ * order and runs the epilogue - nobody waits.  Deterministic, but another association than the one-tile launch (stream-K
+ * proper is bit-identical to it), so it is its own flag: the host sets it for inference plans only.  Ignored where the
+ * launch has tiles enough, where fewer than 4 K-steps per part would be left, or with the fused backward reductions. */
+#define VD_CONV_SPLITK   4096
 #define VD_SK_MAX_WG        2048     /* seam counters per workspace (the last one counts the polls that gave up: diagnostics) */
-#define VD_SK_HEADER_BYTES  16384    /* [VD_SK_MAX_WG] u32 hand-off counters + [VD_SK_MAX_WG] u32 consumed counts */
+#define VD_SK_HEADER_BYTES  32768    /* [VD_SK_MAX_WG] u32 hand-off counters + [VD_SK_MAX_WG] u32 consumed counts + [VD_SK_SPLIT_MAX_TILES] u32 arrivals */
+#define VD_SK_SPLIT_CNT_OFF   4096   /* (u32 words) the split-K form's per-tile arrival counters: zero between launches */
+#define VD_SK_SPLIT_MAX_TILES 4096
 #define VD_SK_TIMEOUT_TICKS 4000     /* bound of the hand-off poll in 10 ns ticks, after which the consumer recomputes */
 #define VD_AMAX_SLOTS    32
 #define VD_AMAX_STRIDE   64   /* floats between sub-slots (256 B) */
@@ -102,7 +111,7 @@ int vd_version(void);
  * header would have passed its stream handle as amax_out).  A binding checks vd_abi_version() == VD_ABI_VERSION and
  * vd_sizeof_desc(i) == sizeof(its mirror of the descriptor) at load, before the first compute call: viddet_amd/lib.py
  * does, INTEGRATION.md shows it.  i: 0 = vd_conv_desc, 1 = vd_wgrad_desc, 2 = vd_head_desc; unknown i -> -1. */
-#define VD_ABI_VERSION 5
+#define VD_ABI_VERSION 6
 int vd_abi_version(void);
 int64_t vd_sizeof_desc(int which);
 
@@ -167,7 +176,8 @@ typedef struct {
     float*  amax_out;
     /* VD_CONV_STREAMK: hand-off workspace, vd_conv_igemm_streamk_ws_bytes() bytes.  The caller zeroes its first
      * VD_SK_HEADER_BYTES ONCE, when it allocates it (the counters are monotonic across launches), and never shares one
-     * workspace between launches that may run at the same time (one per stream). */
+     * workspace between launches that may run at the same time (one per stream).  VD_CONV_SPLITK uses the same workspace
+     * (its per-tile arrival counters are zero between launches). */
     void*   sk_ws;
     int64_t sk_ws_bytes;
     /* VD_CONV_PARITY4: channels per parity class, nonzero (tap, class) weight blocks */
@@ -194,7 +204,9 @@ int vd_conv_igemm_mtiles(const vd_conv_desc* d);
  * them.  d->tile: 0 = default, 1..13 = tile variant (256x256 .. 128x64; the host autotunes it). */
 int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream);
 /* VD_CONV_STREAMK in d->flags (with sk_ws / sk_ws_bytes) runs the launch as a persistent stream-K grid where that form
- * applies (bf16 outputs, Ci % 64 == 0, enough tiles: as vd_conv_igemm); 1 when vd_conv_igemm_bf16(d, out_f32) would. */
+ * applies (bf16 outputs, Ci % 64 == 0, enough tiles: as vd_conv_igemm), VD_CONV_SPLITK as a split-K grid where THAT
+ * applies (too few tiles for the chip).  Returns 1 when vd_conv_igemm_bf16(d, out_f32) would run the stream-K form, 2 when
+ * it would run the split-K form, 0 when it would launch one workgroup per tile. */
 int vd_conv_igemm_bf16_streamk(const vd_conv_desc* d, int out_f32);
 int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d);
 /* fp32 fwd-packed [>=Co][T*Ci] -> bf16 [Co_pad][T*Ci_pad] (zero padded rows / channels) */

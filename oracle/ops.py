@@ -49,8 +49,10 @@ def conv2d_backward(x, w, dy, stride=1, pad=0):
     o, _, kh, kw = w.shape
     cols, ho, wo = _im2col(x, kh, kw, stride, pad)
     dy2 = dy.reshape(n, o, ho * wo)
-    dw = np.einsum('nop,nkp->ok', dy2, cols.reshape(n, c * kh * kw, ho * wo)).reshape(w.shape)
-    dcols = np.einsum('ok,nop->nkp', w.reshape(o, -1), dy2).reshape(n, c, kh, kw, ho, wo)
+    cols2 = cols.reshape(n, c * kh * kw, ho * wo)
+    # dw[o,k] = sum_n sum_p dy[n,o,p] cols[n,k,p];  dcols[n,k,p] = sum_o w[o,k] dy[n,o,p]   (per-frame BLAS products)
+    dw = np.tensordot(dy2, cols2, axes=([0, 2], [0, 2])).reshape(w.shape)
+    dcols = np.matmul(w.reshape(o, -1).T[None], dy2).reshape(n, c, kh, kw, ho, wo)
     dxp = np.zeros((n, c, h + 2 * pad, wd + 2 * pad), dtype=x.dtype)
     for ky in range(kh):
         for kx in range(kw):

@@ -120,14 +120,36 @@ def test_configs1_detect_batch_32_frames_608(precision):
     _frames_identical(net, bufs, B, c, min_tensors=70)
     for t in (idsB, scB, bxB, rowsB):
         assert bool((t == t[0:1]).all())
-    # against the batch-1 run: the same rows in the same order, except where two scores tie to the 6th digit
+    if precision == 'bf16':
+        # against the batch-1 run.  Its 19 x 19 / 38 x 38 layers run as split-K grids (VD_CONV_SPLITK: 24 tiles cannot fill the
+        # chip), i.e. the same fp32 sums in another association, and a bf16 rounding that lands one unit away in a layer is the
+        # noise floor of bf16 storage - so the comparison is the one bf16 inference is held to against the fp32 oracle
+        # (tests/test_bf16_gpu.py): raw heads within 3e-2 of the head's largest magnitude (measured 0.9e-2 / 1.4e-2: two runs that
+        # each sit ~1.2e-2 from the oracle), the
+        # batch-1 run's ten best detections found again with the same class and IoU > 0.9
+        b1 = net._programs[('infer_bf16', 1, size, size)][1]
+        for hname in net.head_names:
+            a, b_ = b1[hname][..., :3 * (5 + c)].float(), bufs[hname][:1, ..., :3 * (5 + c)].float()
+            rel = float((a - b_).abs().max()) / float(a.abs().max())
+            print(hname, "batch 1 vs batch 32 (bf16): max difference / max|head| = %.2e" % rel)
+            assert rel < 3e-2, (hname, rel)
+        i1, s1, q1 = ids1.cpu().numpy()[0, :, 0], sc1.cpu().numpy()[0, :, 0], bx1.cpu().numpy()[0]
+        iB, qB = idsB.cpu().numpy()[0, :, 0], bxB.cpu().numpy()[0]
+        for j in [j for j in range(len(i1)) if i1[j] >= 0][:10]:
+            best = 0.0
+            for q in np.nonzero(iB == i1[j])[0]:
+                a, b_ = q1[j], qB[q]
+                iw, ih = max(0.0, min(a[2], b_[2]) - max(a[0], b_[0])), max(0.0, min(a[3], b_[3]) - max(a[1], b_[1]))
+                u = (a[2] - a[0]) * (a[3] - a[1]) + (b_[2] - b_[0]) * (b_[3] - b_[1]) - iw * ih
+                best = max(best, iw * ih / u if u > 0 else 0.0)
+            assert best > 0.9, (j, s1[j], best)
+        return
+    # fp32, against the batch-1 run: the same rows in the same order, except where two scores tie to the 6th digit
     from tests.util import assert_rows_match, take_ranks
-    tie = 1e-6 if precision == 'fp32' else 2e-3   # bf16: another tile shape may round a layer's output differently
-    perm = assert_rows_match(rowsB[:1].cpu().numpy(), rows1.cpu().numpy(), sc1.cpu().numpy(), tie=tie)
-    tol = 1e-5 if precision == 'fp32' else 2e-2
+    perm = assert_rows_match(rowsB[:1].cpu().numpy(), rows1.cpu().numpy(), sc1.cpu().numpy(), tie=1e-6)
     assert np.array_equal(take_ranks(idsB[:1], perm), ids1.cpu().numpy())
-    assert float(np.abs(take_ranks(scB[:1], perm) - sc1.cpu().numpy()).max()) < tol
-    assert float(np.abs(take_ranks(bxB[:1], perm) - bx1.cpu().numpy()).max()) < (3e-3 if precision == 'fp32' else 2.0)
+    assert float(np.abs(take_ranks(scB[:1], perm) - sc1.cpu().numpy()).max()) < 1e-5
+    assert float(np.abs(take_ranks(bxB[:1], perm) - bx1.cpu().numpy()).max()) < 3e-3
 
 
 def test_configs3_temporal_windows_batch_16_416():

@@ -333,12 +333,13 @@ def test_data_parallel_two_ranks_equal_one_process():
     # three consecutive steps (momentum, the repacked weight layouts and max-abs slots after each update), bit-identical
     # ... and bf16-storage training (BASELINE configs[4]'s mode: 8 GPUs, bf16) under the same SyncBN('all') + bucketed
     # all-reduce: duplicate shards bit-identical over two steps, real shards within the bf16 tolerance
-    for extra in (dict(VD_DP_DUP="1"), dict(), dict(VD_DP_DUP="1", VD_DP_K="3", VD_DP_SCOPE="reference"),
-                  dict(VD_DP_K="3"), dict(VD_DP_DUP="1", VD_DP_STEPS="3"),
-                  dict(VD_DP_STORAGE="bf16", VD_DP_DUP="1", VD_DP_STEPS="2"), dict(VD_DP_STORAGE="bf16")):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
-                           text=True, timeout=600, env=dict(base, **extra))
-        assert r.returncode == 0 and "dp_equivalence ok" in r.stdout, (extra, r.stdout[-800:], r.stderr[-1500:])
+    # (one set of processes runs the seven cases one after the other: a process start costs more than a case)
+    import json
+    cases = [dict(DUP=1), dict(), dict(DUP=1, K=3, SCOPE="reference"), dict(K=3), dict(DUP=1, STEPS=3),
+             dict(STORAGE="bf16", DUP=1, STEPS=2), dict(STORAGE="bf16")]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_equivalence.py"), "2"], capture_output=True,
+                       text=True, timeout=900, env=dict(base, VD_DP_CASES=json.dumps(cases)))
+    assert r.returncode == 0 and r.stdout.count("dp_equivalence ok") == len(cases), (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_single_rank_rccl_path_and_exchange_diagnostics():

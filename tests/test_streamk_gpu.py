@@ -280,3 +280,66 @@ def test_bf16_kernel_bit_identical(case, tile):
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b)
     assert int(ws.view(torch.int32)[2047]) == 0
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 10])
+@pytest.mark.parametrize("case", [(1, 512, 19, 1024, 3), (1, 1024, 19, 512, 1), (1, 256, 38, 512, 3), (2, 128, 38, 256, 3),
+                                  (1, 1024, 13, 256, 1), (1, 384, 13, 256, 1)])
+def test_bf16_split_k_of_launches_with_too_few_tiles(case, tile):
+    """VD_CONV_SPLITK (batch-1 detection: 24 tiles of 128 x 128 on 256 CUs): K cut into 2..8 parts per tile, summed in part
+    order by the part that arrives last.  Not the one-tile launch's association, so the claims are: the fp64 oracle within
+    the bf16 kernel's tolerance, the one-tile launch within one bf16 rounding of the fp32 sums, the same bits on every
+    run (whoever arrives last), the statistics rows of a training-form launch, and counters back at zero."""
+    from viddet_amd import ops, lib as L
+    n, ci, hw, co, k = case
+    g = torch.Generator(device="cuda").manual_seed(977 + tile)
+    x = torch.randn(n, hw, hw, ci, device="cuda", generator=g).to(torch.bfloat16)
+    wt = torch.randn(co, k * k * ci, device="cuda", generator=g) / np.sqrt(ci * k * k)
+    wb = torch.empty(co, k * k * ci, device="cuda", dtype=torch.bfloat16)
+    ops.pack_weight_bf16(wt, wb, Co=co, Co_pad=co, Ci=ci, Ci_pad=ci, T=k * k)
+    res = torch.randn(n, hw, hw, co, device="cuda", generator=g).to(torch.bfloat16)
+    sc, sh = torch.rand(co, device="cuda", generator=g) + 0.5, torch.randn(co, device="cuda", generator=g)
+    ws = ops.streamk_workspace()
+    geo = dict(N=n, Hi=hw, Wi=hw, Ci=ci, Hg=hw, Wg=hw, in_stride=1, taps=ops.fwd_taps(k, k // 2), Ho=hw, Wo=hw, Co=co, ldo=co, tile=tile)
+    # fp64 reference on the bf16 operands: packed weight layout [co][tap][ci] -> OIHW
+    x64 = x.float().permute(0, 3, 1, 2).double().cpu().numpy()
+    w64 = wb.float().reshape(co, k, k, ci).permute(0, 3, 1, 2).double().cpu().numpy()
+    ref = R.conv2d(x64, w64, 1, k // 2)
+    S = R.conv2d(np.abs(x64), np.abs(w64), 1, k // 2)
+    hit = 0
+    for nohalo in ((False, True) if k == 3 else (True,)):
+        z0 = torch.empty(n, hw, hw, co, device="cuda", dtype=torch.bfloat16)
+        p0 = torch.zeros(ops.conv_bf16_mtiles(n, hw, hw, ci, co, tile), 2 * co, device="cuda")
+        ops.conv_igemm_bf16(x, wb, z0, stats_part=p0, nohalo=nohalo, **geo)
+        y0 = torch.empty_like(z0)
+        ops.conv_igemm_bf16(x, wb, y0, scale=sc, shift=sh, residual=res, ldr=co, leaky=True, nohalo=nohalo, **geo)
+        runs = []
+        for rep in range(3):
+            z = torch.empty_like(z0)
+            part = torch.zeros_like(p0)
+            d = ops.conv_igemm_bf16(x, wb, z, stats_part=part, nohalo=nohalo, streamk_ws=ws, splitk=True, **geo)
+            form = int(L.load().vd_conv_igemm_bf16_streamk(C.byref(d), 0))
+            y = torch.empty_like(z0)
+            ops.conv_igemm_bf16(x, wb, y, scale=sc, shift=sh, residual=res, ldr=co, leaky=True, nohalo=nohalo, streamk_ws=ws, splitk=True, **geo)
+            runs.append((z, part, y))
+        torch.cuda.synchronize()
+        if form != 2:
+            assert form == 0 and all(torch.equal(a, b) for a, b in zip(runs[0], (z0, p0, y0)))      # flag ignored: the same launch
+            continue
+        hit += 1
+        for r in runs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], r)), "split-K: run-to-run bits"
+        z, part, y = runs[0]
+        got = z.float().permute(0, 3, 1, 2).cpu().numpy()
+        # fp32 accumulation of bf16 products in K / S chains, then one bf16 rounding of the result
+        assert np.all(np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-5 * S + 1e-30), float(np.abs(got - ref).max())
+        # against the one-tile launch: the fp32 sums differ by summation order (<= ~1e-6 sum|a||b|), so the bf16 outputs differ
+        # by at most one bf16 unit, on few elements
+        dz = (z.float() - z0.float()).abs()
+        assert float((dz / z0.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7 and float((dz > 0).float().mean()) < 0.02
+        dy = (y.float() - y0.float()).abs()
+        assert float((dy / y0.float().abs().clamp_min(1e-2)).max()) <= 2.0 ** -6
+        assert torch.allclose(part, p0, rtol=2e-5, atol=2e-5 * float(p0.abs().max()))
+    assert int(ws.view(torch.int32)[L.SK_HEADER_BYTES // 8:L.SK_HEADER_BYTES // 4].abs().max()) == 0      # arrival counters back at zero
+    if tile in (1, 2, 3, 4, 5) and n * hw * hw <= 1500 and k * k * ci // 64 >= 8:      # (fewer than 4 K-steps per part: not cut)
+        assert hit > 0, "the split-K form was expected to apply here"

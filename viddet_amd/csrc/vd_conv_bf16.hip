@@ -26,8 +26,9 @@ void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
         return launch_b<4, 2, 2, 1, OUT_F32, true>(d, s);
     }
     if (tile <= 0 || tile > 15) tile = d.Co <= 32 ? 12 : (d.Co <= 64 ? 10 : 2);
-    // VD_CONV_STREAMK: the persistent stream-K grid of the same tile (vd_conv_bf16_sk.hip) where it applies
-    if (!OUT_F32 && (d.flags & VD_CONV_STREAMK) && vd_igemm_bf16_sk_dispatch(d, tile, s, false) == 0) return;
+    // VD_CONV_STREAMK / VD_CONV_SPLITK: the persistent stream-K grid, or the split-K grid, of the same tile
+    // (vd_conv_bf16_sk.hip) where one of them applies
+    if (!OUT_F32 && (d.flags & (VD_CONV_STREAMK | VD_CONV_SPLITK)) && vd_igemm_bf16_sk_dispatch(d, tile, s, false) == 0) return;
     switch (tile) {
         // 14, 15: small four-wave tiles (37 / 28 KB of LDS: four or five workgroups per CU) for the short-K 1x1 layers, which
         // are HBM-bound and ran at half the HBM rate on the large tiles: one workgroup's load latency and output stores
@@ -121,10 +122,11 @@ static int bf16_tile_bm(const vd_conv_desc& d) {
 }
 
 int vd_conv_igemm_bf16_streamk(const vd_conv_desc* d, int out_f32) {
-    if (!d || out_f32 || !(d->flags & VD_CONV_STREAMK) || d->Ci == 32) return 0;
+    if (!d || out_f32 || !(d->flags & (VD_CONV_STREAMK | VD_CONV_SPLITK)) || d->Ci == 32) return 0;
     int tile = d->tile;
     if (tile <= 0 || tile > 15) tile = d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2);
-    return vd_igemm_bf16_sk_dispatch(*d, tile, nullptr, true) == 0 ? 1 : 0;
+    const int r = vd_igemm_bf16_sk_dispatch(*d, tile, nullptr, true);
+    return r == 0 ? 1 : (r == 2 ? 2 : 0);
 }
 
 int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d) {
@@ -142,6 +144,8 @@ int vd_conv_igemm_bf16(const vd_conv_desc* d, int out_f32, void* stream) {
                "vd_conv_igemm_bf16: bad sizes");
     VD_REQUIRE(!(d->flags & VD_EPI_RESIDUAL) || (d->residual && d->ldr >= d->Co), "vd_conv_igemm_bf16: residual missing");
     VD_REQUIRE(!d->in_scale, "vd_conv_igemm_bf16: the in-load transform is an fp32-path feature");
+    VD_REQUIRE(!(d->flags & (VD_CONV_STREAMK | VD_CONV_SPLITK)) || !d->sk_ws || ((uintptr_t)d->sk_ws % 16 == 0 && d->sk_ws_bytes >= VD_SK_HEADER_BYTES),
+               "vd_conv_igemm_bf16: stream-K / split-K workspace misaligned or smaller than its header");
     if (d->bs_part) {
         const int t_ = (d->Ci == 32) ? 0 : ((d->tile <= 0 || d->tile > 15) ? (d->Co <= 32 ? 12 : (d->Co <= 64 ? 10 : 2)) : d->tile);
         VD_REQUIRE(!out_f32 && t_ != 8 && t_ != 9, "vd_conv_igemm_bf16: fused backward reductions need a bf16 output and a tile other than 8 / 9");

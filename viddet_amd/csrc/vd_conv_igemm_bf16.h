@@ -55,9 +55,16 @@ struct RowInfoB {
 // SK: the persistent stream-K form (vd_conv_bf16_sk.hip) - equal runs of (tile, K-unit) units per workgroup, the tile a run
 // boundary cuts finished by the next workgroup FROM the first one's accumulators (same MFMA chain, bit-identical outputs).
 // The scheme, its hand-off protocol and its rationale are k_conv_igemm's (vd_conv_igemm.h); only the storage type differs.
+// SK with sk_split = S >= 2: the SPLIT-K form for launches with too few tiles to fill the chip (batch-1 detection: 24 tiles of
+// 128 x 128 at 19 x 19).  Workgroup b computes K-units [upt part / S, upt (part + 1) / S) of tile b / S (part = b % S),
+// publishes its raw accumulators (the stream-K hand-off: write-through stores, drain, barrier, one relaxed agent-scope
+// atomic), and the workgroup whose atomic finds S - 1 earlier arrivals resets the tile's counter, acquires, sums the S
+// partials IN PART ORDER (its own read back like the others: one code path, a fixed association whoever arrives last) and
+// runs the epilogue; the others exit.  Nobody waits for anybody: no poll, no co-residency requirement.  Deterministic, but
+// NOT the association of the one-tile launch (S chains of K / S products summed, instead of one chain of K).
 template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR, bool HALO = false, bool BS = false, bool SK = false>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_desc p, const int64_t zd_in,
-                                                                  const int64_t zd_w, const int sk_lds_flag, const int sk_timeout) {
+                                                                  const int64_t zd_w, const int sk_lds_flag, const int sk_timeout, const int sk_split) {
     static_assert(!HALO || (WM * WN == 8 && !PAIR), "the halo loop exists for the 8-wave tiles");
     static_assert(!SK || !PAIR, "stream-K: not for the two-taps-per-step first-stage tiles");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     constexpr int KU = HALO ? 9 : 1;                       // K-steps per schedulable unit (HALO: one 64-channel chunk)
     const int upt = PAIR ? (p.T + 1) / 2 : p.T * (p.Ci / KCH) / KU;
     int sk_nitems = 1, sk_t0 = 0, sk_nwhole = 0, sk_brem = 0, sk_erem = 0, sk_tlast = 0, sk_tfirst = 0, sk_me = 0;
-    if (SK) {
+    if (SK && sk_split == 0) {
         const int G = (int)gridDim.x, g = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int gq = G >> 3, gr = G & 7;
         const int gs = gq + (g < gr ? 1 : 0);
@@ -124,7 +131,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
     if (SK) {
         __syncthreads();                      // the previous item's epilogue is done with LDS
         const bool hasA = sk_erem != 0;
-        if (hasA && sk_it == 0) { lid = sk_tlast; ke = sk_erem; sk_mode = 1; }
+        if (sk_split > 0) {                   // split-K: one (tile, part) per workgroup
+            const int part = (int)blockIdx.x % sk_split;
+            lid = (int)blockIdx.x / sk_split;
+            kb = upt * part / sk_split;
+            ke = upt * (part + 1) / sk_split;
+            sk_me = (int)blockIdx.x;
+            sk_mode = 3;
+        }
+        else if (hasA && sk_it == 0) { lid = sk_tlast; ke = sk_erem; sk_mode = 1; }
         else if (sk_it - (hasA ? 1 : 0) < sk_nwhole) lid = sk_t0 + sk_it - (hasA ? 1 : 0);
         else { lid = sk_tfirst; kb = sk_brem; sk_mode = 2; }
     }
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
 
     STAMP(4);
     if (SK) {
-        if (sk_mode == 1) {                   // publish the K-prefix: raw accumulators, write-through, one counter bump
+        if (sk_mode == 1 || sk_mode == 3) {   // publish raw accumulators (a K-prefix, or a split's part): write-through, drained
             char* slot = reinterpret_cast<char*>(p.sk_ws) + VD_SK_HEADER_BYTES + (int64_t)sk_me * (BM * BN * 4);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slot, 0, BM * BN * 4, 0x00027000);
             typedef int v4i_ __attribute__((ext_vector_type(4)));
@@ -513,9 +528,47 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm_bf16(const vd_conv_
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0)
-                __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.sk_ws) + sk_me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+            if (sk_mode == 1) {               // stream-K: one counter bump, the next workgroup of the group takes it from here
+                if (tid == 0)
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.sk_ws) + sk_me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            // split-K: the last part to arrive finishes the tile
+            int* lds_flag = reinterpret_cast<int*>(smem_b + sk_lds_flag);
+            if (tid == 0) {
+                unsigned* tcnt = reinterpret_cast<unsigned*>(p.sk_ws) + VD_SK_SPLIT_CNT_OFF + lid;
+                const unsigned old = __hip_atomic_fetch_add(tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == (unsigned)(sk_split - 1);
+                if (last) {
+                    __hip_atomic_store(tcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                *lds_flag = last;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!*lds_flag) continue;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            const f32x4* part0 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.sk_ws) + VD_SK_HEADER_BYTES +
+                                                                (int64_t)lid * sk_split * (BM * BN * 4));
+            for (int sp = 0; sp < sk_split; ++sp) {
+                const f32x4* ps = part0 + (int64_t)sp * (BM * BN / 4);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = ps[((mi * TN + ni) * 4 + q) * NT + tid];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[mi][ni][4 * q + e] += v[e];
+                        }
+            }
         }
     }
     // ---- epilogue (fp32 math).  Per wave, one 32x32
@@ -829,7 +882,30 @@ inline int streamk_grid_b(const vd_conv_desc& d, int BM, int BN, int wg_per_cu) 
     return G;
 }
 
-// returns 0 when launched; 1 when SK was asked for and does not apply (the caller launches the classic form)
+// split-K factor of a launch whose tiles cannot fill the chip (see the kernel's header comment), or 0: at least two parts, at
+// most 8 (the finishing workgroup reads S x BM x BN x 4 bytes alone), at least `min_units` K-units per part, no more
+// workgroups than the chip holds at once (so that the parts of a tile run together), a counter and a slot per (tile, part)
+inline int splitk_factor_b(const vd_conv_desc& d, int BM, int BN, int wg_per_cu, int upt, int min_units) {
+    if (!(d.flags & VD_CONV_SPLITK) || !d.sk_ws || wg_per_cu < 1) return 0;
+    static const int off = getenv("VD_SPLITK") ? !atoi(getenv("VD_SPLITK")) : 0;
+    if (off) return 0;
+    auto al = [](const void* q, int a) { return (uintptr_t)q % a == 0; };
+    if (d.ldo % 4 || d.Co % 4 || !al(d.out, 16) || ((d.flags & VD_EPI_RESIDUAL) && (d.ldr % 4 || !al(d.residual, 8))) ||
+        ((d.flags & VD_EPI_AFFINE) && (!al(d.scale, 16) || !al(d.shift, 16))))
+        return 0;
+    const int64_t ntiles = vd_cdiv((int64_t)d.N * d.Hg * d.Wg, BM) * vd_cdiv(d.Co, BN);
+    const int64_t slots = (int64_t)device_cus_b() * wg_per_cu;
+    if (ntiles > VD_SK_SPLIT_MAX_TILES || ntiles * 2 > slots) return 0;
+    int64_t S = slots / ntiles;
+    if (S > upt / min_units) S = upt / min_units;
+    if (S > 8) S = 8;
+    if (S < 2) return 0;
+    if (d.sk_ws_bytes < (int64_t)VD_SK_HEADER_BYTES + ntiles * S * BM * BN * 4) return 0;
+    return (int)S;
+}
+
+// returns 0 when launched; 1 when SK was asked for and does not apply (the caller launches the classic form); query_only:
+// 0 = would launch as a stream-K grid, 2 = as a split-K grid, 1 = neither
 template <int WM, int WN, int TM, int TN, bool OUT_F32, bool PAIR = false, bool HALO = false, bool BS = false, bool SK = false>
 int launch_b2(const vd_conv_desc& d, hipStream_t s, bool query_only = false) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -844,7 +920,7 @@ int launch_b2(const vd_conv_desc& d, hipStream_t s, bool query_only = false) {
     }
     const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
     int64_t nblk = vd_cdiv(M, BM) * vd_cdiv(d.Co, BN);
-    int sk_flag_off = 0;
+    int sk_flag_off = 0, sk_split = 0;
     if (SK) {
         lds = (lds + 15) & ~15;
         if (lds + 16 > 160 * 1024) return 1;
@@ -852,17 +928,25 @@ int launch_b2(const vd_conv_desc& d, hipStream_t s, bool query_only = false) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kfn), WM * WN * 64, lds + 16) != hipSuccess) per_cu = 0;
         const int G = streamk_grid_b(d, BM, BN, per_cu > 2 ? 2 : per_cu);       // (at most two per CU: more only shrink the runs)
-        if (G == 0) return 1;
-        if (query_only) return 0;
+        if (G == 0) {
+            // too few tiles for a stream-K grid: the split-K form, where its conditions hold (K-units: a 64-channel chunk of
+            // nine steps in the halo loop - at least one per part; at least four K-steps per part otherwise)
+            const int upt = d.T * (d.Ci / KCH) / (HALO ? 9 : 1);
+            sk_split = BS ? 0 : splitk_factor_b(d, BM, BN, per_cu > 4 ? 4 : per_cu, upt, HALO ? 1 : 4);
+            if (sk_split == 0) return 1;
+            nblk *= sk_split;
+        } else {
+            nblk = G;
+        }
+        if (query_only) return sk_split ? 2 : 0;
         sk_flag_off = lds;
         lds += 16;
-        nblk = G;
     }
     const __bf16* zp = reinterpret_cast<const __bf16*>(zero_page_b());
     const int64_t zd_in = zp - reinterpret_cast<const __bf16*>(d.in);
     const int64_t zd_w = zp - reinterpret_cast<const __bf16*>(d.wp);
     static const int sk_timeout = getenv("VD_SK_TIMEOUT_TICKS") ? atoi(getenv("VD_SK_TIMEOUT_TICKS")) : VD_SK_TIMEOUT_TICKS;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w, sk_flag_off, sk_timeout);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, d, zd_in, zd_w, sk_flag_off, sk_timeout, sk_split);
     return 0;
 }
 

@@ -20,6 +20,12 @@ namespace {
 constexpr int TOPK_MAX = 512;
 constexpr int SORT_N = 1024;
 constexpr int NMS_THREADS = 1024;
+// developer timing probe (tools/nms_probe.sh): -DVD_NMS_PROBE=n ends k_nms after phase n (results are garbage)
+#ifndef VD_NMS_PROBE
+#define VD_NMS_PROBE 0
+#endif
+// (the exit stores something that depends on the phase's LDS results, or the compiler removes the phase)
+#define NMS_PROBE_EXIT(n, expr) do { if (VD_NMS_PROBE == (n)) { out_rows[(int64_t)blockIdx.x * post_nms + (threadIdx.x % post_nms)] = (int)(expr); return; } } while (0)
 
 struct Box { float x1, y1, x2, y2; };
 
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
     __shared__ float bx1[TOPK_MAX], by1[TOPK_MAX], bx2[TOPK_MAX], by2[TOPK_MAX];
     __shared__ int bcls[TOPK_MAX];
     __shared__ unsigned long long smask[TOPK_MAX * (TOPK_MAX / 64)];
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int s_prefix_hi, s_prefix_lo, s_kth, s_cnt;
+    __shared__ unsigned int wtot[NMS_THREADS / 64];
+    __shared__ unsigned int s_prefix_hi, s_prefix_lo, s_kth, s_cnt, s_rows_done;
     __shared__ int keep[TOPK_MAX];
     __shared__ int s_nkeep;
 
@@ -315,9 +321,9 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
         // i.e. score descending, then ORIGINAL ROW ascending - the order a stable sort of the reference's
         // (B, C*P, 6) tensor gives.  Rows are unique, so keys are unique and exactly `topk` keys are
         // >= the selected one: rows tied at the threshold score are kept by row order, never by arrival order.
-        if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_kth = (unsigned)topk; }
+        if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_kth = (unsigned)topk; s_rows_done = 0; }
         // The candidates' score bits are read ONCE, NLOC per thread, all requests in flight together (lists of up to
-        // NLOC x 1024 = 40960 candidates: 37 k per image at batch 32 / 608x608 with the calibrated 2 % pass rate); the nine
+        // NLOC x 1024 = 40960 candidates: 37 k per image at batch 32 / 608x608 with the calibrated 2 % pass rate); the
         // sweeps below then run out of registers.  Reading them again from global memory in every sweep - one dependent L2
         // round trip per 1024 candidates and sweep behind the LDS atomics - was ~90 us of this kernel's 220.  Longer lists
         // keep the streaming form.
@@ -329,21 +335,28 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
             const int i = tid + j * NMS_THREADS;
             kreg[j] = (loc && i < n) ? __float_as_uint(cs[i]) : 0u;
         }
-        for (int pass = 7; pass >= 0; --pass) {
-            if (tid < 256) hist[tid] = 0;
+        // Digits of 12, 12 and 8 bits, most significant first: three sweeps for the score, then - ONLY when the rows tied at
+        // the threshold score are not all taken - three for the row.  (Eight 8-bit digits were 76 us of this kernel's 153:
+        // scores of one image share their top byte but for four or five values, so the first sweep's 37 k LDS atomics fell on
+        // as many addresses and ran one lane at a time; twelve bits reach three mantissa bits - ~50 bins - and the second
+        // digit is spread over all 4096.  The histogram borrows the IoU table's LDS, unused until the select is over.)
+        unsigned* hist = reinterpret_cast<unsigned*>(smask);
+        for (int pass = 0; pass < 6; ++pass) {
+            const int sub = pass < 3 ? pass : pass - 3;
+            const int sh = sub == 0 ? 20 : (sub == 1 ? 8 : 0), wd = sub == 2 ? 8 : 12;
+            const int nb = 1 << wd;
+            for (int i = tid; i < nb; i += NMS_THREADS) hist[i] = 0;
             __syncthreads();
+            if (s_rows_done) break;                     // (uniform: written two barriers ago)
             const unsigned phi = s_prefix_hi, plo = s_prefix_lo;
             auto digit = [&](int i, unsigned k) {
-                if (pass >= 4) {                       // score digits: prefix = the digits above this one
-                    const int hs = 8 * (pass - 3);
-                    if (pass == 7 || (k >> hs) == phi) atomicAdd(&hist[(k >> (8 * (pass - 4))) & 255u], 1u);
-                } else if (k == phi) {                 // row digits, only among rows tied at the threshold score
+                if (pass < 3) {                         // score digits: prefix = the digits above this one
+                    if (pass == 0 || (k >> (sh + wd)) == phi) atomicAdd(&hist[(k >> sh) & (unsigned)(nb - 1)], 1u);
+                } else if (k == phi) {                  // row digits, only among rows tied at the threshold score
                     const unsigned r = 0xFFFFFFFFu - (unsigned)cr[i];
-                    const int hs = 8 * (pass + 1);
-                    if (pass == 3 || (r >> hs) == plo) atomicAdd(&hist[(r >> (8 * pass)) & 255u], 1u);
+                    if (pass == 3 || (r >> (sh + wd)) == plo) atomicAdd(&hist[(r >> sh) & (unsigned)(nb - 1)], 1u);
                 }
             };
-            // (wave-aggregated atomics for the leading digit - four or five distinct values - measured no faster: 0.165 vs 0.157 ms)
             if (loc) {
 #pragma unroll
                 for (int j = 0; j < NLOC; ++j) {
@@ -354,44 +367,45 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
                 for (int i = tid; i < n; i += NMS_THREADS) digit(i, __float_as_uint(cs[i]));
             }
             __syncthreads();
-            // the digit of the kth-largest key: the largest d >= 1 whose suffix count S(d) = sum_{b >= d} hist[b] reaches kth
-            // (else 0), by ONE wave - four bins per lane, a suffix scan over the lanes.  (One thread walking the 256 bins was a
-            // chain of 256 dependent LDS reads per sweep: ~8 us x 8 sweeps of a kernel whose whole budget is 200.)
-            if (tid < 64) {
+            // the digit of the kth-largest key: the bin d with S(d) >= kth > S(d + 1), S(d) = sum_{b >= d} hist[b] (bin 0 when
+            // nothing reaches kth).  Four bins per thread (one 16-byte read), a suffix scan over the lanes, the waves' totals
+            // through LDS; the one thread that holds the boundary publishes it.
+            {
                 const unsigned kth = s_kth;
-                const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                const unsigned t = h0 + h1 + h2 + h3;
-                unsigned suf = t;                                   // inclusive suffix sum over lanes >= this one
+                const int lane_ = tid & 63, wave_ = tid >> 6;
+                uint4 hv = make_uint4(0u, 0u, 0u, 0u);
+                if (4 * tid < nb) hv = *reinterpret_cast<const uint4*>(hist + 4 * tid);
+                const unsigned t = hv.x + hv.y + hv.z + hv.w;
+                unsigned suf = t;                                   // inclusive suffix sum over the lanes >= this one
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const unsigned o = __shfl_down(suf, off);
-                    if (tid + off < 64) suf += o;
+                    if (lane_ + off < 64) suf += o;
                 }
-                const unsigned S3 = suf - t + h3, S2 = S3 + h2, S1 = S2 + h1, S0 = S1 + h0;
-                int dl = -1;
-                unsigned above = 0;                                 // S(dl + 1)
-                if (S3 >= kth) { dl = 4 * tid + 3; above = suf - t; }
-                else if (S2 >= kth) { dl = 4 * tid + 2; above = S3; }
-                else if (S1 >= kth) { dl = 4 * tid + 1; above = S2; }
-                else if (S0 >= kth && tid > 0) { dl = 4 * tid; above = S1; }
-                const unsigned long long has = __ballot(dl >= 1);
-                int d = 0;
-                unsigned cum;
-                if (has) {
-                    const int top = 63 - (int)__builtin_clzll(has);
-                    d = __builtin_amdgcn_readlane(dl, top);
-                    cum = (unsigned)__builtin_amdgcn_readlane((int)above, top);
-                } else {
-                    cum = (unsigned)__builtin_amdgcn_readlane((int)S1, 0);        // nothing reaches kth above bin 0: S(1)
+                if (lane_ == 0) wtot[wave_] = suf;
+                __syncthreads();
+                unsigned above = suf - t;                           // S(4 tid + 4)
+                for (int w2 = wave_ + 1; w2 < NMS_THREADS / 64; ++w2) above += wtot[w2];
+                const unsigned S3 = above + hv.w, S2 = S3 + hv.z, S1 = S2 + hv.y, S0 = S1 + hv.x;
+                int d = -1;
+                unsigned cum = 0, tied = 0;
+                if (4 * tid < nb) {
+                    if (S3 >= kth && above < kth) { d = 4 * tid + 3; cum = above; tied = hv.w; }
+                    else if (S2 >= kth && S3 < kth) { d = 4 * tid + 2; cum = S3; tied = hv.z; }
+                    else if (S1 >= kth && S2 < kth) { d = 4 * tid + 1; cum = S2; tied = hv.y; }
+                    else if ((S0 >= kth || tid == 0) && S1 < kth) { d = 4 * tid; cum = S1; tied = hv.x; }
                 }
-                if (tid == 0) {
-                    if (pass >= 4) s_prefix_hi = (phi << 8) | (unsigned)d;
-                    else s_prefix_lo = (plo << 8) | (unsigned)d;
+                if (d >= 0) {
+                    if (pass < 3) s_prefix_hi = (phi << wd) | (unsigned)d;
+                    else s_prefix_lo = (plo << wd) | (unsigned)d;
                     s_kth = kth - cum;
+                    // the score is complete and every row tied at it is wanted: no row digits (Tr = 0 takes them all)
+                    if (pass == 2 && kth - cum == tied) s_rows_done = 1;
                 }
             }
             __syncthreads();
         }
+        __syncthreads();
         const unsigned Ts = s_prefix_hi, Tr = s_prefix_lo;
         auto take = [&](int i, unsigned k) {
             if (k < Ts) return;
@@ -412,6 +426,7 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
         }
     }
     __syncthreads();
+    NMS_PROBE_EXIT(1, skey[tid]);
     // bitonic sort ascending: (~score, row) => score descending, original row ascending on ties
     for (int k = 2; k <= SORT_N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -424,12 +439,14 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
             __syncthreads();
         }
     }
+    NMS_PROBE_EXIT(2, skey[tid]);
     int nsel = n < topk ? n : topk;
     if (nsel > SORT_N) nsel = SORT_N;
     // re-decode the survivors' boxes from the head tensor
     const int R0 = h.g[0] * h.g[0], R1 = h.g[1] * h.g[1];
     const int base1 = h.C * 3 * R0, base2 = h.C * 3 * (R0 + R1);
     const int npred = 5 + h.C;
+    for (int idx = tid; idx < TOPK_MAX * (TOPK_MAX / 64); idx += NMS_THREADS) smask[idx] = 0ull;   // (was the select's histogram)
     if (tid < nsel) {
         const int row = (int)(unsigned int)(skey[tid] & 0xffffffffull);
         int s, rr;
@@ -446,41 +463,92 @@ __global__ __launch_bounds__(NMS_THREADS) void k_nms(const vd_head_desc h, const
         bcls[tid] = c;
     }
     __syncthreads();
+    NMS_PROBE_EXIT(3, bx1[tid & (TOPK_MAX - 1)] + (float)bcls[tid & (TOPK_MAX - 1)]);
     const int nw = (nsel + 63) >> 6;
-    for (int idx = tid; idx < nsel * nw; idx += NMS_THREADS) {
-        const int i = idx / nw, w = idx - i * nw;
-        const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i];
-        const float aarea = (ax2 - ax1) * (ay2 - ay1);
-        const int ac = bcls[i];
-        unsigned long long bits = 0;
-        for (int jj = 0; jj < 64; ++jj) {
-            const int j = w * 64 + jj;
-            if (j <= i || j >= nsel || bcls[j] != ac) continue;
-            const float iw = fmaxf(0.f, fminf(ax2, bx2[j]) - fmaxf(ax1, bx1[j]));
-            const float ih = fmaxf(0.f, fminf(ay2, by2[j]) - fmaxf(ay1, by1[j]));
-            const float inter = iw * ih;
-            const float uni = aarea + (bx2[j] - bx1[j]) * (by2[j] - by1[j]) - inter;
-            const float iou = uni <= 0.f ? 0.f : inter / uni;
-            if (iou > nms_thresh) bits |= (1ull << jj);
+    // IoU bitmask, word w of row i = the columns j in [64 w, 64 w + 64) that row i suppresses (j > i, same class, IoU above
+    // the threshold).  A lane owns ONE column of the word (its box in registers), a wave walks the rows that can have bits in
+    // that word (i < 64 w + 64) and a ballot IS the word: no inner loop over columns, the row's box is a broadcast LDS read.
+    // (One thread per (row, word) looping over its 64 columns was 33 us of this kernel; words below the diagonal were
+    // zeroed with the boxes above.)
+    {
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        for (int w = 0; w < nw; ++w) {
+            const int j = w * 64 + lane_;
+            const bool jv = j < nsel;
+            const int jc = jv ? j : 0;
+            const float cx1 = bx1[jc], cy1 = by1[jc], cx2 = bx2[jc], cy2 = by2[jc];
+            const int ccls = bcls[jc];
+            const int iend = nsel < (w + 1) * 64 ? nsel : (w + 1) * 64;
+            for (int i = wave_; i < iend; i += NMS_THREADS / 64) {
+                // columns of this word the row can suppress at all: behind it in the order, same class.  One workgroup is
+                // one CU: the phase is bound by its VALU, so a row with no such column (most rows, with tens of classes
+                // among the top-k) costs a compare and a ballot, and the test itself is inter > thresh * union - the
+                // same predicate as inter / union > thresh without the division's dozen instructions
+                const unsigned long long cand = __ballot(jv && j > i && ccls == bcls[i]);
+                if (cand == 0ull) continue;                      // (the table was zeroed above)
+                const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i];
+                const float aarea = (ax2 - ax1) * (ay2 - ay1);
+                const float iw = fmaxf(0.f, fminf(ax2, cx2) - fmaxf(ax1, cx1));
+                const float ih = fmaxf(0.f, fminf(ay2, cy2) - fmaxf(ay1, cy1));
+                const float inter = iw * ih;
+                const float uni = aarea + (cx2 - cx1) * (cy2 - cy1) - inter;
+                const bool bit = ((cand >> lane_) & 1ull) && uni > 0.f && inter > nms_thresh * uni;
+                const unsigned long long m = __ballot(bit);
+                if (lane_ == 0) smask[i * (TOPK_MAX / 64) + w] = m;
+            }
         }
-        smask[i * (TOPK_MAX / 64) + w] = bits;
     }
     __syncthreads();
-    // greedy sweep by one wave: lane w owns removed-word w
+    NMS_PROBE_EXIT(4, smask[tid]);
+    // greedy sweep by one wave, 64 rows at a time.  Inside a chunk the decisions depend on each other only through the
+    // chunk's OWN word of its rows' masks: lane l holds that word of row 64 c + l and a scalar loop walks the 64 bits
+    // (v_readlane with a constant lane, no LDS round trip per row); the kept rows' other words are then OR-ed into the removed set - independent
+    // LDS reads, lane w owning word w.  (One dependent shuffle + LDS read per row: 38 us for 400 rows.)
     if (tid < 64) {
         unsigned long long removed = 0;
         int nkeep = 0;
-        for (int i = 0; i < nsel; ++i) {
-            const unsigned long long wordi = __shfl(removed, i >> 6);
-            if (!((wordi >> (i & 63)) & 1ull)) {
-                if (tid == 0) keep[nkeep] = i;
-                ++nkeep;
-                if (tid < nw) removed |= smask[i * (TOPK_MAX / 64) + tid];
+        for (int c = 0; c < nw; ++c) {
+            const int i0 = c * 64;
+            const int cnt = nsel - i0 < 64 ? nsel - i0 : 64;
+            const unsigned long long diag = tid < cnt ? smask[(i0 + tid) * (TOPK_MAX / 64) + c] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned rlo = (unsigned)removed, rhi = (unsigned)(removed >> 32);
+            unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rhi, c) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)rlo, c);
+            // (rows past the chunk's count start out "removed"; straight-line and branch-free: one wave issues an instruction
+            // every four or five cycles and pays ~16 for a taken branch, which made the looped form 110 cycles per row)
+            if (cnt < 64) cur |= ~0ull << cnt;
+            unsigned long long keepbits = 0;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) {
+                const unsigned long long alive = ((cur >> l) & 1ull) ^ 1ull;
+                const unsigned long long dl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, l) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)dlo, l);
+                keepbits |= alive << l;
+                cur |= dl & (0ull - alive);
             }
+            if ((keepbits >> tid) & 1ull) keep[nkeep + __popcll(keepbits & ((1ull << tid) - 1ull))] = i0 + tid;
+            // (eight rows' words requested together, then masked by the rows' keep bits: one LDS round trip per eight rows
+            // instead of one per kept row)
+            unsigned long long acc = 0;
+            const int wl = tid < nw ? tid : 0;
+            for (int l0 = 0; l0 < cnt; l0 += 8) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                  // (rows past the chunk's count: their keep bit is clear)
+                    const int rq = i0 + l0 + q < TOPK_MAX ? i0 + l0 + q : TOPK_MAX - 1;
+                    v[q] = smask[rq * (TOPK_MAX / 64) + wl];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc |= ((keepbits >> (l0 + q)) & 1ull) ? v[q] : 0ull;
+            }
+            removed |= acc;
+            nkeep += __popcll(keepbits);
         }
         if (tid == 0) s_nkeep = nkeep;
     }
     __syncthreads();
+    NMS_PROBE_EXIT(5, keep[tid & (TOPK_MAX - 1)] + s_nkeep);
     const int nkeep = s_nkeep;
     for (int j = tid; j < post_nms; j += NMS_THREADS) {
         const int64_t o = (int64_t)b * post_nms + j;

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VD_LIB: developer override for A/B-testing a differently built kernel library (tools/ only)
 LIB_PATH = os.environ.get("VD_LIB") or os.path.join(_HERE, "csrc", "libviddet_hip.so")
 
-ABI_VERSION = 5          # include/viddet_hip.h VD_ABI_VERSION
+ABI_VERSION = 6          # include/viddet_hip.h VD_ABI_VERSION
 VD_MAX_TAPS = 27
 EPI_AFFINE, EPI_LEAKY, EPI_RESIDUAL = 1, 2, 4
 MATH_SPLIT = 16        # vd_conv_desc.flags / vd_wgrad_desc.flags: split-operand fp32 products (include/viddet_hip.h)
@@ -20,8 +20,9 @@ MATH_NOHALO = 128      # with MATH_F16X2: generic K loop instead of the halo-sta
 STORE_BF16 = 256       # vd_wgrad_desc.flags: `in` / `dout` are bf16 tensors (bf16-storage training)
 WGRAD_HALO = 512       # vd_wgrad_desc.flags: halo-ring kernel for 3x3 / stride-1 weight gradients (vd_wgrad_halo.hip)
 CONV_STREAMK = 1024    # vd_conv_desc.flags: persistent stream-K grid (vd_conv_sk.hip); bit-identical results
+CONV_SPLITK = 4096     # vd_conv_desc.flags (vd_conv_igemm_bf16): split-K for launches with too few tiles; deterministic, not bit-identical
 CONV_PARITY4 = 2048    # vd_conv_desc.flags: a 3x3 / stride-2 data gradient as ONE launch (vd_conv_par.hip)
-SK_HEADER_BYTES = 16384
+SK_HEADER_BYTES = 32768
 AMAX_SLOTS, AMAX_STRIDE = 32, 64
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE      # floats of one tensor's max-abs slots (include/viddet_hip.h)
 

@@ -114,8 +114,9 @@ class Program:
                         meta["bytes_epilogue_reads"] = extra
                         meta["bytes"] = meta["bytes"] + extra
                 if fname == "vd_conv_igemm_bf16":
+                    form = int(L.load().vd_conv_igemm_bf16_streamk(args[0], args[1]))
                     meta = dict(meta or {}, tile=int(args[0]._obj.tile), nohalo=bool(args[0]._obj.flags & L.MATH_NOHALO),
-                                streamk=bool(L.load().vd_conv_igemm_bf16_streamk(args[0], args[1])))
+                                streamk=form == 1, splitk=form == 2)
                 out.append((fname, meta, e0, e1))
             else:
                 rc = fn(*a, s)
@@ -512,14 +513,16 @@ def autotune_wgrad(d, ws_ptr, ws_bytes, reps=2):
     d.flags = _TUNE_CACHE[key]
 
 
-def _tune_bf16_record(d, of32, key, tiles, halo_geo):
+def _tune_bf16_record(d, of32, key, tiles, halo_geo, splitk=False):
     """Time the tile variants of one vd_conv_igemm_bf16 launch record in place - generic loop, halo-staged loop where it
     exists, and the persistent stream-K form of the three fastest (VD_CONV_STREAMK: same bits) - and keep the best as
-    (tile, flag bits) under `key`."""
+    (tile, flag bits) under `key`.  splitk (inference plans only - the form is deterministic but has another summation
+    order than the one-tile launch): launches with too few tiles for the chip also time the split-K grid (VD_CONV_SPLITK)
+    of every tile that has one."""
     import os
     lib = L.load()
     s = L.stream_ptr()
-    mask = L.MATH_NOHALO | L.CONV_STREAMK
+    mask = L.MATH_NOHALO | L.CONV_STREAMK | L.CONV_SPLITK
     base = d.flags & ~mask
     if key not in _TUNE_CACHE:
         verbose = os.environ.get("VD_TUNE_VERBOSE") == "1"
@@ -537,7 +540,8 @@ def _tune_bf16_record(d, of32, key, tiles, halo_geo):
             if verbose:
                 fl_ = 2.0 * d.N * d.Hg * d.Wg * d.Co * d.T * d.Ci * 3 / t / 1e9
                 print("bf16 tune %s tile %d %s%s: %.3f ms %.0f TF" % (key[1:10], c, "generic" if fl & L.MATH_NOHALO else "halo",
-                                                                   " stream-K" if fl & L.CONV_STREAMK else "", t / 3, fl_), flush=True)
+                                                                   " split-K" if fl & L.CONV_SPLITK else " stream-K" if fl & L.CONV_STREAMK else "",
+                                                                   t / 3, fl_), flush=True)
             return t
         ranked = []
         for c in tiles:
@@ -545,10 +549,16 @@ def _tune_bf16_record(d, of32, key, tiles, halo_geo):
                 ranked.append((time_of(c, fl), (c, fl)))
         ranked.sort()
         if _streamk_on() and d.sk_ws and not of32:
-            for _, (c, fl) in list(ranked[:3]):
+            classic = list(ranked)
+            for _, (c, fl) in classic[:3]:
                 d.tile, d.flags = c, base | fl | L.CONV_STREAMK
-                if lib.vd_conv_igemm_bf16_streamk(C.byref(d), of32):
+                if lib.vd_conv_igemm_bf16_streamk(C.byref(d), of32) == 1:
                     ranked.append((time_of(c, fl | L.CONV_STREAMK), (c, fl | L.CONV_STREAMK)))
+            if splitk and os.environ.get("VD_SPLITK", "1") != "0":
+                for _, (c, fl) in classic:
+                    d.tile, d.flags = c, base | fl | L.CONV_SPLITK
+                    if lib.vd_conv_igemm_bf16_streamk(C.byref(d), of32) == 2:
+                        ranked.append((time_of(c, fl | L.CONV_SPLITK), (c, fl | L.CONV_SPLITK)))
             ranked.sort()
         _TUNE_CACHE[key] = _TUNE_CACHE.agree(ranked[0][1] if ranked else (2, L.MATH_NOHALO))
     d.tile, d.flags = _TUNE_CACHE[key][0], base | _TUNE_CACHE[key][1]
@@ -1603,7 +1613,7 @@ class YOLOV3(object):
             if fname != 'vd_conv_igemm_bf16':
                 continue
             d, of32 = args[0]._obj, args[1]
-            base = d.flags & ~(L.MATH_NOHALO | L.CONV_STREAMK)
+            base = d.flags & ~(L.MATH_NOHALO | L.CONV_STREAMK | L.CONV_SPLITK)
             key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.Kfr)
             one = d.T == 1           # 14 / 15: small four-wave tiles for the HBM-bound 1x1 layers
             tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
@@ -1612,7 +1622,7 @@ class YOLOV3(object):
             # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
             # does not apply) is timed against the generic one
             halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0
-            _tune_bf16_record(d, of32, key, tiles, halo_geo)
+            _tune_bf16_record(d, of32, key, tiles, halo_geo, splitk=True)
         _TUNE_CACHE.save()
 
     # ------------------------------------------------------------------ inference

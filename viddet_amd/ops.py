@@ -147,9 +147,10 @@ def conv_fwd(x, wp, out, *, k, stride, pad, Co, ldo=None, scale=None, shift=None
 
 def conv_igemm_bf16(x, wb, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, Wo, Co, ldo, out_stride=1, out_oy=0, out_ox=0,
                     scale=None, shift=None, residual=None, ldr=0, leaky=False, slope=0.1, tile=0, stats_part=None, nohalo=False,
-                    streamk_ws=None):
+                    streamk_ws=None, splitk=False):
     """vd_conv_igemm_bf16: x / wb / residual bf16, out bf16 or fp32 (by its dtype); any output geometry; stats_part =
-    fused BatchNorm statistics table [mtiles][2 * Co] (conv_bf16_mtiles)."""
+    fused BatchNorm statistics table [mtiles][2 * Co] (conv_bf16_mtiles).  streamk_ws: VD_CONV_STREAMK (bit-identical);
+    splitk=True with it: VD_CONV_SPLITK too (launches with too few tiles for the chip are cut along K)."""
     d = ConvDesc()
     d.tile = tile
     d.in_, d.wp, d.out = ptr(x), ptr(wb), ptr(out)
@@ -162,7 +163,7 @@ def conv_igemm_bf16(x, wb, out, *, N, Hi, Wi, Ci, Hg, Wg, in_stride, taps, Ho, W
               (EPI_RESIDUAL if residual is not None else 0) | (MATH_NOHALO if nohalo else 0)
     d.slope, d.stats_part = slope, ptr(stats_part)
     if streamk_ws is not None:
-        d.flags |= L.CONV_STREAMK
+        d.flags |= L.CONV_STREAMK | (L.CONV_SPLITK if splitk else 0)
         d.sk_ws, d.sk_ws_bytes = ptr(streamk_ws), streamk_ws.numel() * streamk_ws.element_size()
     check(_lib().vd_conv_igemm_bf16(C.byref(d), 1 if out.dtype == torch.float32 else 0, _s()), "vd_conv_igemm_bf16")
     return d
