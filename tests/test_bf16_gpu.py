@@ -34,6 +34,12 @@ _BF16_CASES += [(14, (2, 128, 9, 9, 64, 1, 1, 0)), (14, (2, 64, 13, 11, 128, 1, 
 _BF16_CASES += [(12, (2, 64, 21, 19, 32, 1, 1, 0)), (12, (2, 64, 12, 12, 24, 3, 1, 1)), (0, (2, 64, 21, 19, 32, 1, 1, 0)),
                 (0, (2, 64, 17, 15, 64, 3, 1, 1)), (0, (2, 64, 17, 15, 256, 3, 1, 1))]
 
+# 16: the first-stage patch kernel (vd_conv_c32_bf16.hip: 32 -> 64 channels, 3x3, stride 1 / 2): maps narrower and wider than a
+# 32-pixel patch, heights that are not multiples of the patch's 8 / 4 rows, odd sizes under stride 2, one full-width row of the
+# 608 x 608 frame's 304-wide map; (out_f32 and shapes it does not serve fall back to the generic tiles: same assertions)
+_BF16_CASES += [(16, sh) for sh in [(2, 32, 19, 21, 64, 3, 1, 1), (2, 32, 18, 20, 64, 3, 2, 1), (1, 32, 33, 70, 64, 3, 1, 1),
+                                    (3, 32, 41, 67, 64, 3, 2, 1), (1, 32, 9, 304, 64, 3, 1, 1), (1, 32, 17, 608, 64, 3, 2, 1),
+                                    (2, 32, 8, 32, 64, 3, 1, 1), (3, 32, 40, 24, 40, 3, 1, 1)]]
 
 # halo-staged loop (3x3 stride 1 on the 8-wave tiles): several 64-channel chunks, maps wider than a tile's rows and narrower,
 # frames ending inside a tile, the 76- and 152-wide maps of the 608x608 detection path; every case also with the flag that

@@ -13,6 +13,8 @@
 #include "vd_conv_igemm_bf16.h"
 
 int vd_igemm_bf16_sk_dispatch(const vd_conv_desc& d, int tile, hipStream_t s, bool query_only);     // vd_conv_bf16_sk.hip
+bool vd_conv_c32_bf16_ok(const vd_conv_desc& d, bool out_f32);                                       // vd_conv_c32_bf16.hip
+void vd_conv_c32_bf16_launch(const vd_conv_desc& d, hipStream_t s);
 
 namespace {
 
@@ -20,6 +22,8 @@ template <bool OUT_F32>
 void dispatch_b(const vd_conv_desc& d, hipStream_t s) {
     int tile = d.tile;
     if (d.Ci == 32) {                                          // two taps per K-step; these layers have Co = 64
+        // 16: the first-stage patch kernel (vd_conv_c32_bf16.hip: 2-D patches staged once, weights in registers) where it applies
+        if (tile == 16 && vd_conv_c32_bf16_ok(d, OUT_F32)) return vd_conv_c32_bf16_launch(d, s);
         if (tile == 11) return launch_b<4, 1, 2, 2, OUT_F32, true>(d, s);
         if (tile == 13) return launch_b<2, 2, 2, 1, OUT_F32, true>(d, s);
         if (tile == 14) return launch_b<2, 2, 1, 1, OUT_F32, true>(d, s);     // 64 x 64, four waves (short-K 1x1: see tile 14 below)

@@ -149,7 +149,7 @@ class TuneCache(dict):
         # the conv kernels' sources (the public header is not part of it: declarations of other entry points change there
         # without touching a tile; descriptor layouts are guarded by the ABI revision)
         srcs = [os.path.join(here, "csrc", f) for f in ("vd_conv.hip", "vd_conv_igemm.h", "vd_conv_sk.hip", "vd_conv_par.hip",
-                                                         "vd_conv_bf16.hip", "vd_conv_igemm_bf16.h", "vd_conv_bf16_sk.hip",
+                                                         "vd_conv_bf16.hip", "vd_conv_igemm_bf16.h", "vd_conv_bf16_sk.hip", "vd_conv_c32_bf16.hip",
                                                          "vd_wgrad_halo.hip", "vd_common.h")]
         h = hashlib.sha256()
         if all(os.path.exists(f) for f in srcs):
@@ -1616,7 +1616,10 @@ class YOLOV3(object):
             base = d.flags & ~(L.MATH_NOHALO | L.CONV_STREAMK | L.CONV_SPLITK)
             key = ('bf16', d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride, d.T, d.Co, base, of32, d.Kfr)
             one = d.T == 1           # 14 / 15: small four-wave tiles for the HBM-bound 1x1 layers
-            tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+            # (16: the first-stage patch kernel of vd_conv_c32_bf16.hip - 3x3, 32 -> 64 channels; the library falls back to the
+            # default tile where it does not apply)
+            tiles = ((10, 11, 13) + ((14,) if one else ()) + ((16,) if (d.T == 9 and d.Co == 64 and not of32) else ()) if d.Ci == 32
+                     else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
                      else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
                      else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if d.Co > 128 else ()) + ((14,) if one else ()))
             # 3x3 stride-1 'same' geometry: the halo-staged loop (8-wave tiles; the library falls back by itself where it
