@@ -142,6 +142,36 @@ def test_forward_conv_with_fused_statistics(tile):
     assert np.allclose(sums[:co], z.sum(axis=(0, 2, 3)), atol=2e-3) and np.allclose(sums[co:], (z ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 21, 37, 1), (2, 41, 67, 2), (1, 8, 304, 1), (2, 17, 70, 2)])
+def test_first_stage_patch_kernel_with_fused_statistics(shape):
+    """tile 16 (vd_conv_c32_bf16.hip) in its training form: raw bf16 outputs of the 32 -> 64 channel 3x3 conv (stride 1 / 2) and
+    one row of partial sums per 2-D PATCH (pixels of a border patch that lie outside the image are not counted)."""
+    from viddet_amd import ops, lib as L
+    import ctypes as C
+    n, h, w, s_ = shape
+    ci, co, k = 32, 64, 3
+    rng = np.random.default_rng(500 + h + w)
+    x = _r(rng.standard_normal((n, ci, h, w)))
+    wt = _r(rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k))
+    z = R.conv2d(x, wt, s_, 1)
+    ho, wo = z.shape[2], z.shape[3]
+    wp32 = torch.empty(co, k * k * ci, device="cuda")
+    ops.pack_weight_fwd(dev(wt), wp32, co)
+    wb = torch.empty(co, k * k * ci, dtype=BF, device="cuda")
+    ops.pack_weight_bf16(wp32, wb, Co=co, Co_pad=co, Ci=ci, Ci_pad=ci, T=k * k)
+    out = torch.empty(n, ho, wo, co, dtype=BF, device="cuda")
+    part = torch.full((n * ((wo + 31) // 32) * ((ho + 3) // 4) + 1, 2 * co), 7.0, device="cuda")
+    d = ops.conv_igemm_bf16(_nhwc_b(x), wb, out, N=n, Hi=h, Wi=w, Ci=ci, Hg=ho, Wg=wo, in_stride=s_, taps=ops.fwd_taps(k, 1), Ho=ho, Wo=wo,
+                            Co=co, ldo=co, tile=16, stats_part=part)
+    rows = int(L.load().vd_conv_igemm_bf16_mtiles(C.byref(d)))
+    torch.cuda.synchronize()
+    assert rows == n * ((wo + 31) // 32) * ((ho + (8 if s_ == 1 else 4) - 1) // (8 if s_ == 1 else 4))      # the patch kernel ran
+    assert bool((part[rows:] == 7.0).all())
+    assert maxdiff(_nchw(out), z) < 2e-4 + np.abs(z).max() * EPS
+    sums = part[:rows].double().sum(dim=0).cpu().numpy()
+    assert np.allclose(sums[:co], z.sum(axis=(0, 2, 3)), atol=2e-3) and np.allclose(sums[co:], (z ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 13, 13, 256, 3, 1, 1), (2, 128, 9, 11, 128, 1, 1, 0), (2, 64, 18, 20, 64, 3, 2, 1),
                                    (2, 64, 16, 16, 32, 1, 1, 0), (3, 32, 12, 12, 64, 3, 1, 1)])
 def test_weight_gradient_from_bf16_operands(shape):

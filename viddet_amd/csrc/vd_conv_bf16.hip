@@ -15,6 +15,7 @@
 int vd_igemm_bf16_sk_dispatch(const vd_conv_desc& d, int tile, hipStream_t s, bool query_only);     // vd_conv_bf16_sk.hip
 bool vd_conv_c32_bf16_ok(const vd_conv_desc& d, bool out_f32);                                       // vd_conv_c32_bf16.hip
 void vd_conv_c32_bf16_launch(const vd_conv_desc& d, hipStream_t s);
+int64_t vd_conv_c32_bf16_tiles(const vd_conv_desc& d);
 
 namespace {
 
@@ -135,6 +136,7 @@ int vd_conv_igemm_bf16_streamk(const vd_conv_desc* d, int out_f32) {
 
 int vd_conv_igemm_bf16_mtiles(const vd_conv_desc* d) {
     if (!d) return 0;
+    if (d->Ci == 32 && d->tile == 16 && vd_conv_c32_bf16_ok(*d, false)) return (int)vd_conv_c32_bf16_tiles(*d);      // one row per patch
     return (int)vd_cdiv((int64_t)d->N * d->Hg * d->Wg, bf16_tile_bm(*d));
 }
 

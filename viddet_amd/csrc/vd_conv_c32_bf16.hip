@@ -78,7 +78,10 @@ __device__ __attribute__((aligned(64))) unsigned long long g_sink_c32[64];
 // epilogue is written for instruction count - no runtime flag, no masked-store branch, nothing per tile that is the same for
 // every tile.  (First build: 13.0 k cycles per tile, of which the epilogue 6.1 k and the request addressing 2.2 k - against
 // 2.3 k of MFMA; tools/stamp_c32.sh.)
-template <int S, bool RES>
+// STATS (the forward of bf16-storage training, vd_conv_desc.stats_part): the raw conv outputs are stored (no epilogue
+// transform) and the tile's per-channel sum / sum of squares of the fp32 accumulators go to row `tile` of the partial table
+// [tiles][2 * 64], as k_conv_igemm_bf16 writes its rows (vd_bn_sum_partials / _sum_finalize finish them in fp64).
+template <int S, bool RES, bool STATS>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc p, const int ntx, const int nty, const int ntiles) {
     using G = C32Geo<S>;
     constexpr int TW = G::TW, TH = G::TH, TM = G::TM, PR = G::PR, PC = G::PC;
@@ -110,11 +113,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
         toff[t] = ((dy + 1) * PC + col) * PXB;
     }
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+    static_assert(!(STATS && RES), "the training forward stores raw outputs");
     f32x4 sc[2], sh[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        sc[ni] = *reinterpret_cast<const f32x4*>(p.scale + ni * 32 + ec4);
-        sh[ni] = *reinterpret_cast<const f32x4*>(p.shift + ni * 32 + ec4);
+        sc[ni] = STATS ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(p.scale + ni * 32 + ec4);
+        sh[ni] = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.shift + ni * 32 + ec4);
     }
     const float slope = p.slope;
     const int lane_a = (lane & 31) * PXB + (lane >> 5) * 16;      // this lane's pixel / k-half within an operand read
@@ -234,6 +238,45 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[mi], wreg[ks + 1][ni], acc[mi][ni], 0, 0, 0);
         }
         C32_STAMP(4);
+        if constexpr (STATS) {
+            // per-channel sum / sum of squares over the tile's pixels inside the image: a lane's column is lane & 31, its 16
+            // rows of a block are patch columns (r & 3) + 8 (r >> 2) + 4 (lane >> 5); half-waves by shuffle, waves through LDS
+            float* red = reinterpret_cast<float*>(smem_c + G::PATCH_B);      // [4 waves][64][2] (the transpose patches, unused yet)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const bool rowok = valid && oy0 + wave * TM + mi < p.Ho;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float v = (rowok && ox0 + px < p.Wo) ? acc[mi][ni][r] : 0.f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lane < 32) {
+                    red[(wave * 64 + ni * 32 + lane) * 2 + 0] = s1;
+                    red[(wave * 64 + ni * 32 + lane) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < 64 && valid) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s1 += red[(w * 64 + tid) * 2 + 0];
+                    s2 += red[(w * 64 + tid) * 2 + 1];
+                }
+                float* dstp = p.stats_part + (int64_t)tile * 128;
+                dstp[tid] = s1;
+                dstp[64 + tid] = s2;
+            }
+            __syncthreads();                              // the patches are free for the transposes
+        }
         // ---- epilogue: a patch row's two 32 x 32 blocks (64 channels) go through the wave's LDS patch together; a lane then
         // owns 4 columns of 4 pixels in each.  Pixels past the image's edge are stored to a sink, not branched around.
 #pragma unroll
@@ -261,13 +304,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
                 __bf16* dst = ok ? ob + ep_out[i] : sink;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    f32x4 tt = v[ni][i] * sc[ni] + sh[ni];
                     bf16x4 o;
+                    if constexpr (STATS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = fmaxf(tt[e], tt[e] * slope);            // LeakyReLU, 0 < slope < 1 (checked on the host)
-                        if constexpr (RES) u += (float)rv[mi][ni][i][e];
-                        o[e] = (__bf16)u;
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[ni][i][e];
+                    } else {
+                        const f32x4 tt = v[ni][i] * sc[ni] + sh[ni];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float u = fmaxf(tt[e], tt[e] * slope);        // LeakyReLU, 0 < slope < 1 (checked on the host)
+                            if constexpr (RES) u += (float)rv[mi][ni][i][e];
+                            o[e] = (__bf16)u;
+                        }
                     }
                     *reinterpret_cast<bf16x4*>(dst + (ok ? ni * 32 : 0)) = o;
                 }
@@ -295,10 +343,10 @@ int cus_c32() {
     return n;
 }
 
-template <int S, bool RES>
+template <int S, bool RES, bool STATS>
 void launch_c32(const vd_conv_desc& d, hipStream_t s) {
     using G = C32Geo<S>;
-    auto kfn = k_conv3x3_c32_bf16<S, RES>;
+    auto kfn = k_conv3x3_c32_bf16<S, RES, STATS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B);
@@ -313,11 +361,11 @@ void launch_c32(const vd_conv_desc& d, hipStream_t s) {
 }  // namespace
 
 // 1 where vd_conv_igemm_bf16 with d->tile == 16 runs this kernel: a 3x3 conv (any tap order within {-1,0,1}^2) of 32 -> 64
-// channels, stride 1 or 2, 'same' padding, bf16 output at stride 1, the vector epilogue's alignment; no fused statistics /
-// backward reductions / temporal taps
+// channels, stride 1 or 2, 'same' padding, bf16 output at stride 1, the vector epilogue's alignment; either the inference
+// cell's epilogue or the training forward's raw output + statistics; no fused backward reductions / temporal taps
 bool vd_conv_c32_bf16_ok(const vd_conv_desc& d, bool out_f32) {
     if (out_f32 || d.Ci != 32 || d.Co != 64 || d.T != 9 || d.Kfr != 1 || (d.in_stride != 1 && d.in_stride != 2)) return false;
-    if (d.out_stride != 1 || d.out_oy || d.out_ox || d.Ho != d.Hg || d.Wo != d.Wg || d.stats_part || d.bs_part || d.in_scale) return false;
+    if (d.out_stride != 1 || d.out_oy || d.out_ox || d.Ho != d.Hg || d.Wo != d.Wg || d.bs_part || d.in_scale) return false;
     if (d.Hg != (d.Hi + d.in_stride - 1) / d.in_stride || d.Wg != (d.Wi + d.in_stride - 1) / d.in_stride) return false;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {
@@ -328,9 +376,14 @@ bool vd_conv_c32_bf16_ok(const vd_conv_desc& d, bool out_f32) {
     auto al = [](const void* q, int a) { return (uintptr_t)q % a == 0; };
     if (d.ldo % 4 || !al(d.out, 8) || !al(d.in, 16) || !al(d.wp, 16)) return false;
     if ((d.flags & VD_EPI_RESIDUAL) && (d.ldr % 4 || !al(d.residual, 8))) return false;
-    // the epilogue is the inference cell's: folded BatchNorm (both vectors) + LeakyReLU with a slope in (0, 1)
-    if (!(d.flags & VD_EPI_AFFINE) || !(d.flags & VD_EPI_LEAKY) || !d.scale || !d.shift || !al(d.scale, 16) || !al(d.shift, 16)) return false;
-    if (!(d.slope > 0.f && d.slope < 1.f)) return false;
+    if (d.stats_part) {
+        // the training forward: raw outputs + the statistics rows, no epilogue transform
+        if (d.flags & (VD_EPI_AFFINE | VD_EPI_LEAKY | VD_EPI_RESIDUAL)) return false;
+    } else {
+        // the inference cell's epilogue: folded BatchNorm (both vectors) + LeakyReLU with a slope in (0, 1) [+ residual]
+        if (!(d.flags & VD_EPI_AFFINE) || !(d.flags & VD_EPI_LEAKY) || !d.scale || !d.shift || !al(d.scale, 16) || !al(d.shift, 16)) return false;
+        if (!(d.slope > 0.f && d.slope < 1.f)) return false;
+    }
     if ((int64_t)d.Hi * d.Wi * 32 >= (1ll << 31) || d.Wi >= (1 << 22) || d.ldo >= (1 << 20) || d.ldr >= (1 << 20)) return false;     // 32-bit offsets inside a frame
     return (int64_t)d.N * ((d.Wo + 31) / 32) * ((d.Ho + 3) / 4) < (1ll << 30);
 }
@@ -341,8 +394,15 @@ extern "C" int vd_debug_c32_stamps(unsigned long long* out) {
 }
 #endif
 
+// rows of the statistics table a launch of this kernel writes (one per patch)
+int64_t vd_conv_c32_bf16_tiles(const vd_conv_desc& d) {
+    const int th = d.in_stride == 1 ? 8 : 4;
+    return (int64_t)d.N * ((d.Wo + 31) / 32) * ((d.Ho + th - 1) / th);
+}
+
 void vd_conv_c32_bf16_launch(const vd_conv_desc& d, hipStream_t s) {
     const bool r = d.flags & VD_EPI_RESIDUAL;
-    if (d.in_stride == 1) { if (r) launch_c32<1, true>(d, s); else launch_c32<1, false>(d, s); }
-    else { if (r) launch_c32<2, true>(d, s); else launch_c32<2, false>(d, s); }
+    if (d.stats_part) { if (d.in_stride == 1) launch_c32<1, false, true>(d, s); else launch_c32<2, false, true>(d, s); }
+    else if (d.in_stride == 1) { if (r) launch_c32<1, true, false>(d, s); else launch_c32<1, false, false>(d, s); }
+    else { if (r) launch_c32<2, true, false>(d, s); else launch_c32<2, false, false>(d, s); }
 }

@@ -2279,7 +2279,9 @@ class YOLOV3(object):
                bool(d.bs_part))
         # 14 / 15: the small four-wave tiles (64x64 / 128x32, four or five workgroups per CU) for the HBM-bound 1x1 layers
         one = d.T == 1
-        tiles = ((10, 11, 13) + ((14,) if one else ()) if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
+        # (16: the first-stage patch kernel, forward with fused statistics; falls back to the default tile where it does not apply)
+        tiles = ((10, 11, 13) + ((14,) if one else ()) + ((16,) if (d.T == 9 and d.Co == 64 and d.stats_part and not d.bs_part and not of32) else ())
+                 if d.Ci == 32 else (12, 10, 11, 13) + ((15,) if one else ()) if d.Co <= 32
                  else (10, 11, 13, 2, 3, 4, 5) + ((14,) if one else ()) if d.Co <= 64
                  else (1, 2, 3, 4, 5, 6, 7) + ((8, 9) if (d.Co > 128 and not d.bs_part) else ()) + ((14,) if one else ()))
         halo_geo = d.T == 9 and d.in_stride == 1 and d.Hg == d.Hi and d.Ci % 64 == 0 and d.out_stride == 1
