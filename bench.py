@@ -258,7 +258,7 @@ def main():
                     seg()
         else:
             prog = net._programs[("infer_bf16" if a.dtype == "bf16" else "infer", B, S, S)][0]
-            recs = prog.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16", "vd_yolo_decode_filter", "vd_nms_topk"})
+            recs = prog.run_timed({"vd_conv_igemm", "vd_conv_igemm_bf16", "vd_stem_conv_c32_bf16", "vd_yolo_decode_filter", "vd_nms_topk"})
             torch.cuda.synchronize()
             # the HBM-bound tail of the detect path (north_star: achieved GB/s on the decode / NMS kernels): algorithmic
             # bytes = the three fp32 head maps read once (B * sum(g^2) * ldh * 4; SURVEY 8d: 7.73 MB/frame at 608 / C = 80)
@@ -286,7 +286,8 @@ def main():
             nsplit = sum(1 for (f_, m, e0, e1) in recs if f_ == "vd_conv_igemm_bf16" and m and m.get("splitk"))
             if nsplit:
                 extra["splitk_launches"] = nsplit       # VD_CONV_SPLITK: launches with too few tiles for the chip, cut along K
-            recs = [("vd_conv_igemm", m, e0, e1) for (f_, m, e0, e1) in recs if f_ in ("vd_conv_igemm", "vd_conv_igemm_bf16")]
+            # (the fused stem + stride-2 conv launch counts as a conv launch: its meta carries both layers' FLOPs)
+            recs = [("vd_conv_igemm", m, e0, e1) for (f_, m, e0, e1) in recs if f_ in ("vd_conv_igemm", "vd_conv_igemm_bf16", "vd_stem_conv_c32_bf16")]
         torch.cuda.synchronize()
         # the stand-alone forward BatchNorm+LeakyReLU passes, and the part of them that belongs to cells whose output feeds
         # ONE convolution only (what fusing the pass into the consumer's gather could remove)

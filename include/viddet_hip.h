@@ -252,6 +252,14 @@ int vd_conv_wgrad_uses_halo(const vd_wgrad_desc* d);
  * leaves the pad channels alone) fp32, or bf16 when out_bf16; flags = VD_EPI_AFFINE /
  * VD_EPI_LEAKY (BN-eval fold + LeakyReLU); stats_part (flags 0, fp32 out): per-block BatchNorm partial sums
  * [vd_stem_conv_blocks()][2*32], finish with vd_bn_sum_partials(). */
+/* bf16 inference: the stem and the stride-2 conv behind it (three_darknet.py:163-164 + :182-183) in ONE launch of the
+ * first-stage patch kernel (vd_conv_c32_bf16.hip): `d` describes the 3x3 / stride-2 / 32 -> 64 channel conv as for
+ * vd_conv_igemm_bf16 (N, Hi = H, Wi = W of the frames; folded BatchNorm + LeakyReLU epilogue, bf16 output; d->in is not
+ * read), the stem's 32-channel map is computed inside the kernel from the fp32 NCHW frames and never stored.  Outputs are
+ * bit-identical to vd_stem_conv(..., VD_EPI_AFFINE | VD_EPI_LEAKY, out_bf16 = 1) followed by vd_conv_igemm_bf16 with tile
+ * 16.  VD_EINVAL where the descriptor is not that conv. */
+int vd_stem_conv_c32_bf16(const float* x_nchw, const float* stem_wp, const float* stem_scale, const float* stem_shift,
+                          float stem_slope, const vd_conv_desc* d, void* stream);
 int vd_stem_conv_blocks(int N, int H, int W);
 int vd_stem_conv(const float* x_nchw, const float* wp, void* out, int ldo, int N, int H, int W, const float* scale,
                  const float* shift, float slope, int flags, int out_bf16, float* stats_part, void* stream);

@@ -85,6 +85,60 @@ def test_conv_bf16_single_layer(tile, shape):
             assert maxdiff(got, ref) < tol, (nohalo, maxdiff(got, ref), tol)
 
 
+@pytest.mark.parametrize("shape", [(2, 38, 70), (1, 64, 608), (3, 41, 67), (1, 9, 33), (2, 16, 64)])
+def test_stem_and_first_stride2_conv_in_one_launch(shape):
+    """vd_stem_conv_c32_bf16: the stem (3 -> 32, folded BN, LeakyReLU, bf16) computed inside the stride-2 conv's patch kernel
+    instead of being stored - the SAME BITS as vd_stem_conv(out_bf16) + vd_conv_igemm_bf16 (frames of odd and even sizes, maps
+    narrower and wider than a patch, the 608-wide row), and the two-launch form itself against the fp64 oracle."""
+    from viddet_amd import ops, lib as L
+    n, h, w = shape
+    rng = np.random.default_rng(700 + h + w)
+    frames = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    w0 = (rng.standard_normal((32, 3, 3, 3)) / np.sqrt(27)).astype(np.float32)
+    s0, b0 = rng.uniform(0.5, 1.5, 32).astype(np.float32), rng.standard_normal(32).astype(np.float32)
+    w1 = _bf16_round(rng.standard_normal((64, 32, 3, 3)) / np.sqrt(288))
+    s1, b1 = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    lib = L.load()
+    xd = dev(frames)
+    wp0 = torch.zeros(32, 32, device="cuda")
+    wp0[:, :27].copy_(dev(w0).permute(0, 2, 3, 1).reshape(32, 27))      # k = (ky * 3 + kx) * 3 + c
+    sc0, sh0, sc1, sh1 = dev(s0), dev(b0), dev(s1), dev(b1)
+    a = torch.empty(n, h, w, 32, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.vd_stem_conv(xd.data_ptr(), wp0.data_ptr(), a.data_ptr(), 32, n, h, w, sc0.data_ptr(), sh0.data_ptr(), 0.1, 1 | 2, 1,
+                             None, L.stream_ptr()), "vd_stem_conv")
+    wp32 = torch.empty(64, 288, device="cuda")
+    ops.pack_weight_fwd(dev(w1), wp32, 64)
+    wb = torch.empty(64, 288, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.vd_pack_weight_bf16(wp32.data_ptr(), wb.data_ptr(), 64, 64, 32, 32, 9, L.stream_ptr()), "pack")
+    outs = []
+    for fused in (False, True):
+        out = torch.empty(n, ho, wo, 64, dtype=torch.bfloat16, device="cuda")
+        d = L.ConvDesc()
+        d.in_, d.wp, d.out = a.data_ptr(), wb.data_ptr(), out.data_ptr()
+        d.N, d.Hi, d.Wi, d.Ci, d.Hg, d.Wg, d.in_stride = n, h, w, 32, ho, wo, 2
+        ops._set_taps(d, ops.fwd_taps(3, 1))
+        d.Kfr, d.Ho, d.Wo, d.Co, d.out_stride, d.ldo, d.ldr, d.tile = 1, ho, wo, 64, 1, 64, 64, 16
+        d.scale, d.shift, d.flags, d.slope = sc1.data_ptr(), sh1.data_ptr(), 1 | 2, 0.1
+        if fused:
+            d.in_ = None
+            L.check(lib.vd_stem_conv_c32_bf16(xd.data_ptr(), wp0.data_ptr(), sc0.data_ptr(), sh0.data_ptr(), 0.1, C.byref(d), L.stream_ptr()),
+                    "vd_stem_conv_c32_bf16")
+        else:
+            L.check(lib.vd_conv_igemm_bf16(C.byref(d), 0, L.stream_ptr()), "vd_conv_igemm_bf16")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    # the two-launch form against fp64 on what the device holds: bf16 stem output, bf16 weights
+    a64 = np.moveaxis(a.float().cpu().numpy(), -1, 1).astype(np.float64)
+    ref = R.leaky(R.conv2d(a64, w1, 2, 1) * s1.reshape(1, -1, 1, 1) + b1.reshape(1, -1, 1, 1))
+    got = np.moveaxis(outs[0].float().cpu().numpy(), -1, 1)
+    assert maxdiff(got, ref) < 2e-4 + np.abs(ref).max() * 2 ** -8
+    # a descriptor that is not that conv is refused
+    d.in_stride = 1
+    assert lib.vd_stem_conv_c32_bf16(xd.data_ptr(), wp0.data_ptr(), sc0.data_ptr(), sh0.data_ptr(), 0.1, C.byref(d), L.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("c,b,size,obj_bias", [(4, 2, 96, -1.0),
                                                (20, 1, 608, -3.0)])     # BASELINE configs[1]: one full 608x608 frame
 def test_bf16_network_inference_close_to_fp32_oracle(c, b, size, obj_bias):

@@ -61,6 +61,16 @@ struct C32Geo {
     static constexpr int PC = S * (TW - 1) + 3;      // input columns: 34 | 65
     static constexpr int PATCH_B = ((PR * PC * PXB + 15) / 16) * 16;
     static constexpr int LDS_B = PATCH_B + 4 * 2 * 32 * SLD * 4;      // + the waves' transpose patches (two 32 x 32 blocks each)
+    static constexpr int LDS_STEM_B = LDS_B + 3 * (PR + 2) * 68 * 4;   // + the STEM form's frame window
+};
+
+// STEM form: what the kernel needs to compute its own input patch - the stem's folded Conv+BN+LeakyReLU output - from the frame
+struct vd_stem_args {
+    const float* x;        // [N][3][H][W] fp32 frames (H = Hi, W = Wi of the conv descriptor)
+    const float* w;        // stem weights, packed [32][32] fp32: row = output channel, k = tap * 3 + channel (k >= 27: zero)
+    const float* scale;    // folded BatchNorm of the stem
+    const float* shift;
+    float slope;
 };
 
 // n / d for d >= 1 with rcp = 0xFFFFFFFF / d + 1 (exact after one correction)
@@ -81,8 +91,14 @@ __device__ __attribute__((aligned(64))) unsigned long long g_sink_c32[64];
 // STATS (the forward of bf16-storage training, vd_conv_desc.stats_part): the raw conv outputs are stored (no epilogue
 // transform) and the tile's per-channel sum / sum of squares of the fp32 accumulators go to row `tile` of the partial table
 // [tiles][2 * 64], as k_conv_igemm_bf16 writes its rows (vd_bn_sum_partials / _sum_finalize finish them in fp64).
-template <int S, bool RES, bool STATS>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc p, const int ntx, const int nty, const int ntiles) {
+// STEM (stride 2, inference): the input patch is not read from memory - it is the stem's output (3 -> 32 channels, 3x3, folded
+// BatchNorm, LeakyReLU, rounded to bf16 exactly as k_stem_fwd<true, true> writes it: bf16 frame values and weights on
+// v_mfma_f32_32x32x16_bf16, two steps of k = tap * 3 + channel) computed here from an 11 x 67 x 3 window of the frame, so the
+// stem's 32-channel map (757 MB at batch 32 / 608 x 608) is neither written nor read.  Bit-identical to the two launches.
+template <int S, bool RES, bool STATS, bool STEM = false>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc p, const int ntx, const int nty, const int ntiles,
+                                                             const vd_stem_args sa) {
+    static_assert(!STEM || (S == 2 && !RES && !STATS), "the fused stem feeds the stride-2 inference conv");
     using G = C32Geo<S>;
     constexpr int TW = G::TW, TH = G::TH, TM = G::TM, PR = G::PR, PC = G::PC;
     constexpr int NCH = PR * PC * 4;                  // 16-byte chunks of a patch
@@ -144,6 +160,38 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
         ep_out[i] = (erow + 8 * i) * p.ldo + ec4;
         ep_res[i] = (erow + 8 * i) * p.ldr + ec4;
     }
+    // STEM: the frame window (3 channels x FR rows x FC columns around the patch, zero outside the frame) in LDS behind the
+    // transpose patches, pitch FP floats; a thread's LF window elements, and per lane the 16 k-values of its two MFMA operands
+    constexpr int FR = PR + 2, FC = PC + 2, FP = 68, NF = 3 * FR * FC, LF = (NF + 255) / 256;
+    float* fwin = reinterpret_cast<float*>(smem_c + G::PATCH_B + 4 * 2 * 32 * SLD * 4);
+    int f_rc[STEM ? LF : 1], f_goff[STEM ? LF : 1], f_lds[STEM ? LF : 1], koff[STEM ? 16 : 1];
+    bf16x8 sb0, sb1;
+    float ssc = 1.f, ssh = 0.f;
+    if constexpr (STEM) {
+#pragma unroll
+        for (int j = 0; j < LF; ++j) {
+            const int e = tid + j * 256;
+            const int ch = e / (FR * FC), rem = e - ch * (FR * FC);
+            const int fr = rem / FC, fc = rem - fr * FC;
+            f_rc[j] = e < NF ? (fr | (fc << 8)) : (0xff | (0x7fffff << 8));
+            f_goff[j] = (ch * p.Hi + fr) * p.Wi + fc;
+            f_lds[j] = e < NF ? (ch * FR + fr) * FP + fc : -1;
+        }
+        const int hh = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = (e < 8 ? 8 * hh : 16 + 8 * hh) + (e & 7);
+            const int tap = k / 3, c = k - 3 * tap;
+            koff[e] = k < 27 ? (c * FR + tap / 3) * FP + tap % 3 : -1;      // window offset of tap (dy, dx) = (tap / 3 - 1, tap % 3 - 1)
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sb0[e] = (__bf16)sa.w[(lane & 31) * 32 + 8 * hh + e];
+            sb1[e] = (__bf16)sa.w[(lane & 31) * 32 + 16 + 8 * hh + e];
+        }
+        ssc = sa.scale[lane & 31];
+        ssh = sa.shift[lane & 31];
+    }
 
     // ---- the input patch of a tile: every request first (16-byte chunks, pixels outside the image read a zero page - never a
     // branch around a request: the compiler could not count what is in flight where the paths merge); the stores to LDS follow
@@ -157,12 +205,25 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
         const int ty = (int)tr - (int)n * nty;
         const int iy0 = S * ty * TH - 1, ix0 = S * tx * TW - 1;
         const bool tv = tile < ntiles;
-        const __bf16* base = in + ((int64_t)((int)n * p.Hi + iy0) * p.Wi + ix0) * 32;
+        if constexpr (STEM) {
+            // the frame window: one float per request, window origin (iy0 - 1, ix0 - 1)
+            const float* fb = sa.x + (int64_t)(int)n * 3 * p.Hi * p.Wi + (int64_t)(iy0 - 1) * p.Wi + (ix0 - 1);
+            const float* zf = reinterpret_cast<const float*>(g_zero_page_c32);
+            static_assert(LF <= LPT, "the window's requests reuse the patch's registers");
 #pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            const int iy = iy0 + (ch_rc[j] & 0xff), ix = ix0 + (ch_rc[j] >> 8);
-            const bool ok = tv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            ld[j] = *reinterpret_cast<const v4i*>(ok ? base + ch_goff[j] : zpage);
+            for (int j = 0; j < LF; ++j) {
+                const int iy = iy0 - 1 + (f_rc[j] & 0xff), ix = ix0 - 1 + (f_rc[j] >> 8);
+                const bool ok = tv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                ld[j][0] = __float_as_int(*(ok ? fb + f_goff[j] : zf));
+            }
+        } else {
+            const __bf16* base = in + ((int64_t)((int)n * p.Hi + iy0) * p.Wi + ix0) * 32;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const int iy = iy0 + (ch_rc[j] & 0xff), ix = ix0 + (ch_rc[j] >> 8);
+                const bool ok = tv && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                ld[j] = *reinterpret_cast<const v4i*>(ok ? base + ch_goff[j] : zpage);
+            }
         }
     };
     // the residual rows of a tile's epilogue pixels (a lane: 4 pixels x 4 columns per 32 x 32 block), one tile ahead as well
@@ -197,9 +258,64 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32_bf16(const vd_conv_desc 
         C32_STAMP(0);
         __syncthreads();                                  // the previous patch's operand reads are over
         C32_STAMP(1);
+        if constexpr (STEM) {
 #pragma unroll
-        for (int j = 0; j < LPT; ++j)
-            if (ch_lds[j] >= 0) *reinterpret_cast<v4i*>(patch + ch_lds[j]) = ld[j];
+            for (int j = 0; j < LF; ++j)
+                if (f_lds[j] >= 0) fwin[f_lds[j]] = __int_as_float(ld[j][0]);
+            __syncthreads();
+            // the stem on the patch's 9 x 65 pixels, 32 at a time: block (row r, column parity) = the 32 pixels of one parity
+            // plane of one patch row - the LDS pixels a tap of the stride-2 conv reads are exactly such a run, so a lane's 16
+            // results land at compile-time offsets from one address - and one last block for the 33rd even column of the nine
+            // rows.  Per block: 16 window reads, two MFMAs, the stem's epilogue per column, 16 two-byte stores.  No branch
+            // around an LDS access (a masked read became saveexec + read + wait: sixteen serial round trips per block, 57 k
+            // cycles per tile in the first build): k >= 27 reads element 0 and is zeroed by a select.
+            const int iy0 = S * oy0 - 1, ix0 = S * ox0 - 1;
+            const int hh = lane >> 5, li = lane & 31;
+            auto stem_block = [&](const int base, unsigned char* const dst0, const int dstep, const int iy_l, const int iystep,
+                                  const int ix_l, const int ixstep, const int nvalid) {
+                // element q of the accumulator = block row rr(q) = (q & 3) + 8 (q >> 2) + 4 hh: stored at dst0 + rr * dstep,
+                // frame pixel (iy_l + rr * iystep, ix_l + rr * ixstep); rows >= nvalid are not stored (dst0 then points at a dump)
+                float gv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) gv[e] = fwin[base + (koff[e] < 0 ? 0 : koff[e])];
+                bf16x8 a0, a1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = koff[e] >= 0 ? gv[e] : 0.f;
+                    if (e < 8) a0[e] = (__bf16)v; else a1[e - 8] = (__bf16)v;
+                }
+                f32x16 sacc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc[q] = 0.f;
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, sb0, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, sb1, sacc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int rq = (q & 3) + 8 * (q >> 2);                    // + 4 hh: folded into dst0 / iy_l / ix_l by the caller
+                    float t = sacc[q] * ssc + ssh;
+                    t = t > 0.f ? t : t * sa.slope;
+                    // the conv's zero padding is a padding of the STEM'S OUTPUT: patch pixels outside the frame are zeros
+                    const bool inside = (unsigned)(iy_l + rq * iystep) < (unsigned)p.Hi && (unsigned)(ix_l + rq * ixstep) < (unsigned)p.Wi;
+                    unsigned char* dst = (rq + 4 * hh < nvalid) ? dst0 + rq * dstep : smem_c + G::PATCH_B + li * 2;
+                    *reinterpret_cast<__bf16*>(dst) = (__bf16)(inside ? t : 0.f);
+                }
+            };
+#pragma unroll 1
+            for (int blk = wave; blk < 2 * PR; blk += 4) {                    // (rolled: five blocks' registers at once spill)
+                const int r = blk >> 1, par = blk & 1;                         // (uniform)
+                stem_block(r * FP + 2 * li + par,
+                           patch + (r * PC + par * ((PC + 1) / 2) + 4 * hh) * PXB + li * 2, PXB,
+                           iy0 + r, 0, ix0 + par + 8 * hh, 2, 32);
+            }
+            if (wave == 2)                                                     // column 64 (the 33rd even one) of the PR rows
+                stem_block((li < PR ? li : PR - 1) * FP + (PC - 1),
+                           patch + (4 * hh * PC + (PC - 1) / 2) * PXB + li * 2, PC * PXB,
+                           iy0 + 4 * hh, 1, ix0 + PC - 1, 0, PR);
+        } else {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j)
+                if (ch_lds[j] >= 0) *reinterpret_cast<v4i*>(patch + ch_lds[j]) = ld[j];
+        }
         __syncthreads();
         C32_STAMP(2);
         request_rv(tile + (int)gridDim.x, rv_next);
@@ -343,19 +459,20 @@ int cus_c32() {
     return n;
 }
 
-template <int S, bool RES, bool STATS>
-void launch_c32(const vd_conv_desc& d, hipStream_t s) {
+template <int S, bool RES, bool STATS, bool STEM = false>
+void launch_c32(const vd_conv_desc& d, hipStream_t s, const vd_stem_args& sa = vd_stem_args{}) {
     using G = C32Geo<S>;
-    auto kfn = k_conv3x3_c32_bf16<S, RES, STATS>;
+    auto kfn = k_conv3x3_c32_bf16<S, RES, STATS, STEM>;
+    constexpr int lds = STEM ? G::LDS_STEM_B : G::LDS_B;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const int ntx = (d.Wo + G::TW - 1) / G::TW, nty = (d.Ho + G::TH - 1) / G::TH;
     const int64_t ntiles = (int64_t)d.N * ntx * nty;
     const int64_t grid = ntiles < (int64_t)cus_c32() ? ntiles : (int64_t)cus_c32();      // persistent: one workgroup per CU
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), G::LDS_B, s, d, ntx, nty, (int)ntiles);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), lds, s, d, ntx, nty, (int)ntiles, sa);
 }
 
 }  // namespace
@@ -405,4 +522,23 @@ void vd_conv_c32_bf16_launch(const vd_conv_desc& d, hipStream_t s) {
     if (d.stats_part) { if (d.in_stride == 1) launch_c32<1, false, true>(d, s); else launch_c32<2, false, true>(d, s); }
     else if (d.in_stride == 1) { if (r) launch_c32<1, true, false>(d, s); else launch_c32<1, false, false>(d, s); }
     else { if (r) launch_c32<2, true, false>(d, s); else launch_c32<2, false, false>(d, s); }
+}
+
+// The stem and the stride-2 conv behind it in ONE launch (bf16 inference): `d` describes the 32 -> 64 channel conv exactly as
+// for vd_conv_igemm_bf16 with tile 16 (d->in is not read: the stem's output is computed inside the kernel from the fp32 NCHW
+// frames); the stem's epilogue is folded BatchNorm + LeakyReLU.  Replaces vd_stem_conv(..., out_bf16 = 1) + vd_conv_igemm_bf16
+// for _conv2d(32, 3, 1, 1) + _conv2d(64, 3, 1, 2), three_darknet.py:163-164,182-183, with bit-identical outputs.
+extern "C" int vd_stem_conv_c32_bf16(const float* x_nchw, const float* stem_wp, const float* stem_scale, const float* stem_shift,
+                                     float stem_slope, const vd_conv_desc* d, void* stream) {
+    VD_REQUIRE(x_nchw && stem_wp && stem_scale && stem_shift && d && d->wp && d->out, "vd_stem_conv_c32_bf16: null pointer");
+    vd_conv_desc dd = *d;
+    if (!dd.in) dd.in = reinterpret_cast<const float*>(x_nchw);      // (alignment check of a pointer that is never read)
+    VD_REQUIRE(dd.in_stride == 2 && !(dd.flags & VD_EPI_RESIDUAL) && !dd.stats_part && vd_conv_c32_bf16_ok(dd, false),
+               "vd_stem_conv_c32_bf16: the descriptor is not the first-stage stride-2 conv (3x3, 32 -> 64 channels, bf16, folded BatchNorm + LeakyReLU)");
+    VD_REQUIRE((int64_t)3 * dd.Hi * dd.Wi < (1ll << 31) && ((uintptr_t)x_nchw % 4 == 0), "vd_stem_conv_c32_bf16: frame size");
+    vd_stem_args sa;
+    sa.x = x_nchw; sa.w = stem_wp; sa.scale = stem_scale; sa.shift = stem_shift; sa.slope = stem_slope;
+    launch_c32<2, false, false, true>(dd, (hipStream_t)stream, sa);
+    VD_CHECK_LAUNCH("vd_stem_conv_c32_bf16");
+    return VD_OK;
 }

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vd_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vd_stem_conv_blocks": (_i, [_i, _i, _i]),
     "vd_stem_conv": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, C.c_float, _i, _i, _p, _p]),
+    "vd_stem_conv_c32_bf16": (_i, [_p, _p, _p, _p, C.c_float, C.POINTER(ConvDesc), _p]),
     "vd_stem_wgrad_ws_bytes": (_i64, [_i, _i, _i]),
     "vd_stem_wgrad": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i64, _p]),
     "vd_preprocess_u8_nhwc": (_i, [_p, _p, _i64, _p]),

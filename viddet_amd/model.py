@@ -1494,6 +1494,7 @@ class YOLOV3(object):
                 bufs[name] = torch.zeros(B * fr, H // div, W // div, cp(c), dtype=BFT, device=dev)
         prog = Program()
         packs = []
+        fuse_stem = None
         if self.noback:
             # the three cached feature maps arrive as fp32 NCHW: NHWC, then one conversion each
             for nm, c_, d_ in ROUTE_TENSORS:
@@ -1527,6 +1528,20 @@ class YOLOV3(object):
                 prog.add('vd_add_bf16', a_.data_ptr(), b_.data_ptr(), o.data_ptr(), o.numel())
                 continue
             if n.stem:
+                # the stem and the stride-2 conv behind it as ONE launch (vd_stem_conv_c32_bf16: the stem's 32-channel map is
+                # computed inside the first-stage patch kernel and never stored; same bits) where that conv is the stem's only
+                # reader; VD_STEM_FUSED=0: two launches
+                users = [m for m in self.nodes if isinstance(m, ConvNode) and (m.src == n.dst or m.residual == n.dst)] + \
+                        [m for m in self.nodes if not isinstance(m, ConvNode) and n.dst in
+                         [getattr(m, a, None) for a in ('src', 'up', 'route', 'a', 'b')]]
+                import os
+                fuse_stem = None
+                if (os.environ.get("VD_STEM_FUSED", "1") != "0" and len(users) == 1 and isinstance(users[0], ConvNode)
+                        and users[0].src == n.dst and users[0].k == 3 and users[0].kd == 1 and users[0].stride == 2
+                        and users[0].cin == 32 and users[0].cout == 64 and users[0].bn and not users[0].residual
+                        and not getattr(users[0], 'tvalid', False)):
+                    fuse_stem = (n, users[0])
+                    continue
                 # fp32 master weights and BN fold on the fp32 VALU, bf16 output (vd_stem.hip)
                 self._add_stem(prog, n, bufs, B, H, W, bufs[n.dst], scale=n.fold_scale, shift=n.fold_shift, leaky=True,
                                bf16=True)
@@ -1570,6 +1585,15 @@ class YOLOV3(object):
                     d.residual = bufs[n.residual].data_ptr()
             d.slope = LEAKY_SLOPE
             prog.hold(d, wb)
+            if fuse_stem is not None and fuse_stem[1] is n:
+                st = fuse_stem[0]
+                meta = self._flops(n, B, H, W, 'fwd')
+                meta['flops'] += self._flops(st, B, H, W, 'fwd')['flops']
+                meta['fused_stem'] = True
+                d.tile = 16
+                prog.add('vd_stem_conv_c32_bf16', bufs['in'].data_ptr(), st.wp.data_ptr(), st.fold_scale.data_ptr(),
+                         st.fold_shift.data_ptr(), LEAKY_SLOPE, C.byref(d), meta=meta)
+                continue
             prog.add('vd_conv_igemm_bf16', C.byref(d), 1 if n.head else 0, meta=self._flops(n, B, H, W, 'fwd'))
             if tvalid:
                 prog.add('vd_frame_slice', out.data_ptr(), bufs[n.dst].data_ptr(), B, n.fr, 1, n.fr - 2, out[0].numel() // 2, 0)
