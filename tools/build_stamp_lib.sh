@@ -9,4 +9,4 @@ F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-function -fno-sl
 /opt/rocm/bin/hipcc $F -c vd_conv_bf16.hip -o ../../build_dbg/vd_conv_bf16.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_dbg/libviddet_stamp.so ../../build_dbg/vd_conv.o \
-    ../../build_dbg/vd_conv_bf16.o vd_stem.o vd_bn.o vd_pointwise.o vd_yolo.o vd_api.o
+    ../../build_dbg/vd_conv_bf16.o vd_conv_sk.o vd_conv_par.o vd_wgrad_halo.o vd_conv_bf16_sk.o vd_conv_c32_bf16.o vd_stem.o vd_bn.o vd_pointwise.o vd_yolo.o vd_api.o

@@ -10,7 +10,7 @@ F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-function -fno-sl
 for n in 1 2 3 4 5; do
   /opt/rocm/bin/hipcc $F -DVD_NMS_PROBE=$n -c viddet_amd/csrc/vd_yolo.hip -o build_dbg/vd_yolo_p$n.o
   (cd viddet_amd/csrc && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_dbg/libviddet_nmsp$n.so vd_conv.o vd_conv_sk.o vd_conv_par.o \
-      vd_wgrad_halo.o vd_conv_bf16.o vd_conv_bf16_sk.o vd_stem.o vd_bn.o vd_pointwise.o ../../build_dbg/vd_yolo_p$n.o vd_api.o)
+      vd_wgrad_halo.o vd_conv_bf16.o vd_conv_bf16_sk.o vd_conv_c32_bf16.o vd_stem.o vd_bn.o vd_pointwise.o ../../build_dbg/vd_yolo_p$n.o vd_api.o)
 done
 for n in 0 1 2 3 4 5; do
   if [ $n = 0 ]; then L=""; else L="build_dbg/libviddet_nmsp$n.so"; fi
